@@ -1,0 +1,11 @@
+"""`minsu3d/common_ops/functions/pointgroup_ops.py:6-36` counterpart.  Unlike the reference (CPU tensors,
+serial host BFS) the clustering runs on the device and the tensors stay there."""
+import torch
+
+from ...backend import get_backend
+
+
+def pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold):
+    """-> (cluster_idxs i32[sumNPoint,2] (cluster_id, point), cluster_offsets i32[nCluster+1])"""
+    with torch.no_grad():
+        return get_backend().pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, int(threshold))

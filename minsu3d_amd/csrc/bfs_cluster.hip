@@ -1,0 +1,398 @@
+// Order-exact breadth-first clustering on the GPU.  Replaces the reference's single-threaded host
+// BFS (bfs_cluster/bfs_cluster.cpp:28-187: pg_find_cc / sg_find_cc / *_get_clusters /
+// fill_cluster_idxs_) and the two PCIe round trips around it (model/pointgroup.py:49-55,62-65).
+//
+// The output must equal the serial FIFO BFS exactly: clusters ordered by seed =
+// smallest not-yet-visited index, members in queue order, and -- when a neighbour list was cut at
+// 1000 entries -- out-edge reachability on a DIRECTED graph.  Plan:
+//
+//   1. weak components  : lock-free union-find over all label-compatible out-edges, larger root
+//                         hooked under smaller (root = smallest member).  Clusters never cross
+//                         a weak component, and a component smaller than the threshold cannot
+//                         contain a surviving cluster, so only big components are expanded.
+//   2. expansion        : persistent 512-thread workgroups pull components from a work list and
+//                         replay the serial algorithm inside each: seeds in ascending index; a
+//                         level-synchronous BFS whose next frontier is built in exactly the
+//                         serial queue order.  For a frontier chunk every out-edge (parent
+//                         position p, slot s) is visited twice: phase A posts atomicMin(claim[j], p),
+//                         phase B lets the edge with claim[j] == p win; winners are compacted in
+//                         (p, s) order by ballot/prefix-sum, which is the order in which the
+//                         serial loop would have pushed them (lists are ascending in j).
+//   3. assembly         : per-seed sizes -> keep flags -> two exclusive scans give cluster ids
+//                         (ascending seed) and output offsets; one pass copies members.
+//
+// All state lives in a caller-provided workspace; the only host traffic is the final 8-byte
+// (nCluster, sumNPoint) read the caller needs to size its tensors.
+#include "common.h"
+#include "scan.h"
+#include "../../include/minsu3d_hip.h"
+
+namespace {
+
+constexpr int BFS_THREADS = 512;
+constexpr int BFS_WAVES = BFS_THREADS / 64;
+constexpr int INT_BIG = 0x7fffffff;
+
+struct Thr {
+    int mode;     // 0 = pg (label test, int threshold), 1 = sg (no label test, float threshold)
+    int thr_i;
+    float thr_f;
+};
+__device__ __forceinline__ bool qualifies(const Thr &t, int size)
+{
+    return t.mode == 0 ? (size >= t.thr_i) : ((float)size >= t.thr_f);  // bfs_cluster.cpp:94 / :121
+}
+
+__device__ __forceinline__ int ld_agent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int uf_find(int *parent, int x)
+{
+    int p = ld_agent(&parent[x]);
+    while (p != x) {
+        const int gp = ld_agent(&parent[p]);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(int *parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        const int hi = max(a, b), lo = min(a, b);
+        if (atomicCAS(&parent[hi], hi, lo) == hi) return;
+    }
+}
+
+__global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited, int *claim, int *cl_size,
+                                int *counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        parent[i] = i;
+        comp_size[i] = 0;
+        visited[i] = 0;
+        claim[i] = INT_BIG;
+        cl_size[i] = 0;
+    }
+    if (i < 8) counters[i] = 0;
+}
+
+// one wave per point, lanes stride its neighbour list
+__global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
+                                                       const int *__restrict__ ball_idx,
+                                                       const int *__restrict__ start_len, int *parent)
+{
+    const int waves = blockDim.x >> 6;
+    for (int i = blockIdx.x * waves + wave_id(); i < N; i += gridDim.x * waves) {
+        const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+        const int lab = thr.mode == 0 ? (int)sem[i] : 0;
+        for (int t = lane_id(); t < ln; t += 64) {
+            const int j = ball_idx[st + t];
+            if (j == i) continue;
+            if (thr.mode == 0 && (int)sem[j] != lab) continue;  // bfs_cluster.cpp:44
+            uf_union(parent, i, j);
+        }
+    }
+}
+
+// roots go to their own array: concurrent path halving may still rewrite parent[] entries with
+// non-root ancestors while this kernel runs
+__global__ void bfs_flatten_kernel(int N, int *parent, int *root, int *comp_size)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int r = uf_find(parent, i);
+    root[i] = r;
+    atomicAdd(&comp_size[r], 1);
+}
+
+__global__ void bfs_select_kernel(int N, Thr thr, const int *__restrict__ root, const int *__restrict__ comp_size,
+                                  int *worklist, int *counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (root[i] == i && qualifies(thr, comp_size[i])) worklist[atomicAdd(&counters[0], 1)] = i;
+}
+
+__device__ __forceinline__ int block_excl_scan_512(int v, int *total, int *s_wave)
+{
+    const int incl = wave_incl_scan(v);
+    if (lane_id() == 63) s_wave[wave_id()] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BFS_WAVES; w++) {
+        const int t = s_wave[w];
+        if (w < wave_id()) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ int block_min_512(int v, int *s_wave)
+{
+    v = wave_min(v);
+    if (lane_id() == 0) s_wave[wave_id()] = v;
+    __syncthreads();
+    int m = INT_BIG;
+#pragma unroll
+    for (int w = 0; w < BFS_WAVES; w++) m = min(m, s_wave[w]);
+    __syncthreads();
+    return m;
+}
+
+// counters: [0] nwork  [1] next work item  [2] scratch cursor
+__global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
+    int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
+    const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ comp_size,
+    const int *__restrict__ worklist, int *counters, int *visited, int *claim, int *scratch_node, int *scratch_seed,
+    int *cl_size, int *cl_start)
+{
+    __shared__ int s_pref[BFS_THREADS + 1];
+    __shared__ int s_st[BFS_THREADS];
+    __shared__ int s_wave[BFS_WAVES];
+    __shared__ int s_bcast[2];
+    const int tid = threadIdx.x;
+    const int nwork = ld_agent(&counters[0]);
+
+    for (;;) {
+        if (tid == 0) s_bcast[0] = atomicAdd(&counters[1], 1);
+        __syncthreads();
+        const int w = s_bcast[0];
+        __syncthreads();
+        if (w >= nwork) break;
+        const int r = worklist[w];
+        const int sz = comp_size[r];
+        if (tid == 0) s_bcast[1] = atomicAdd(&counters[2], sz);
+        __syncthreads();
+        int tail = s_bcast[1];
+        __syncthreads();
+        const int lab = thr.mode == 0 ? (int)sem[r] : 0;
+        int done = 0;
+        int seed = r;  // the root is the smallest member, hence the first seed
+        while (done < sz) {
+            if (done > 0) {
+                // next seed: smallest unvisited member of this component above the previous seed
+                int found = INT_BIG;
+                for (int c = seed + 1; c < N && found == INT_BIG; c += BFS_THREADS) {
+                    const int i = c + tid;
+                    const int cand = (i < N && root[i] == r && visited[i] == 0) ? i : INT_BIG;
+                    found = block_min_512(cand, s_wave);
+                }
+                seed = found;
+                if (seed == INT_BIG) break;  // cannot happen: done < sz guarantees a member is left
+            }
+            const int cluster_start = tail;
+            if (tid == 0) {
+                scratch_node[tail] = seed;
+                scratch_seed[tail] = seed;
+                visited[seed] = 1;
+            }
+            tail += 1;
+            int lvl_begin = cluster_start, lvl_end = tail;
+            __syncthreads();
+            while (lvl_begin < lvl_end) {
+                int new_tail = tail;
+                for (int c0 = lvl_begin; c0 < lvl_end; c0 += BFS_THREADS) {
+                    const int cn = min(BFS_THREADS, lvl_end - c0);
+                    int ln = 0, st = 0;
+                    if (tid < cn) {
+                        const int node = scratch_node[c0 + tid];
+                        st = start_len[node * 2];
+                        ln = start_len[node * 2 + 1];
+                    }
+                    int E;
+                    const int ex = block_excl_scan_512(ln, &E, s_wave);
+                    s_pref[tid] = ex;
+                    s_st[tid] = st;
+                    if (tid == 0) s_pref[BFS_THREADS] = E;
+                    __syncthreads();
+                    // ---- phase A: every out-edge to an unvisited, label-compatible node posts its parent position
+                    int any = 0;
+                    for (int e = tid; e < E; e += BFS_THREADS) {
+                        int lo = 0, hi = cn;  // largest p with pref[p] <= e
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                        }
+                        const int j = ball_idx[s_st[lo] + (e - s_pref[lo])];
+                        if (thr.mode == 0 && (int)sem[j] != lab) continue;
+                        if (visited[j]) continue;
+                        atomicMin(&claim[j], lo);
+                        any = 1;
+                    }
+                    any = __syncthreads_or(any);
+                    if (any) {
+                        // ---- phase B: winners, compacted in (parent position, slot) order
+                        for (int e0 = 0; e0 < E; e0 += BFS_THREADS) {
+                            const int e = e0 + tid;
+                            int win = 0, j = -1;
+                            if (e < E) {
+                                int lo = 0, hi = cn;
+                                while (hi - lo > 1) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                                }
+                                j = ball_idx[s_st[lo] + (e - s_pref[lo])];
+                                const bool ok = (thr.mode != 0 || (int)sem[j] == lab) && visited[j] == 0;
+                                if (ok && ld_agent(&claim[j]) == lo) win = 1;
+                            }
+                            int tot;
+                            const int rank = block_excl_scan_512(win, &tot, s_wave);
+                            if (win) {
+                                scratch_node[new_tail + rank] = j;
+                                scratch_seed[new_tail + rank] = seed;
+                                visited[j] = 1;
+                            }
+                            new_tail += tot;
+                            __syncthreads();
+                        }
+                    }
+                    __syncthreads();
+                }
+                lvl_begin = lvl_end;
+                lvl_end = new_tail;
+                tail = new_tail;
+            }
+            const int size = tail - cluster_start;
+            if (tid == 0) {
+                cl_size[seed] = size;
+                cl_start[seed] = cluster_start;
+            }
+            done += size;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void bfs_keep_kernel(int N, Thr thr, const int *__restrict__ cl_size, int *keep, int *keep_size)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int s = cl_size[i];
+    const int k = (s > 0 && qualifies(thr, s)) ? 1 : 0;
+    keep[i] = k;
+    keep_size[i] = k ? s : 0;
+}
+
+// counters[3] = nCluster, counters[4] = sumNPoint (written by the scans)
+__global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const int *__restrict__ scratch_node,
+                                const int *__restrict__ scratch_seed, const int *__restrict__ cl_size,
+                                const int *__restrict__ cl_start, const int *__restrict__ cid,
+                                const int *__restrict__ out_off, const int *__restrict__ keep_size,
+                                int *__restrict__ cluster_idxs, int *__restrict__ cluster_offsets)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int used = counters[2];
+    if (t < used) {
+        const int seed = scratch_seed[t];
+        if (keep_size[seed] > 0) {
+            const int pos = out_off[seed] + (t - cl_start[seed]);
+            cluster_idxs[pos * 2 + 0] = cid[seed];
+            cluster_idxs[pos * 2 + 1] = scratch_node[t];
+        }
+    }
+    if (t < N && keep_size[t] > 0) cluster_offsets[cid[t]] = out_off[t];
+    if (t == 0) cluster_offsets[counters[3]] = counters[4];
+}
+
+struct BfsWorkspace {
+    int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
+        *keep_size, *cid, *out_off, *counters;
+    void *scan_ws;
+};
+size_t carve(BfsWorkspace &w, int N, void *base)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *r = base ? (void *)((char *)base + off) : nullptr;
+        off += ms3d_align(bytes);
+        return (int *)r;
+    };
+    const size_t nb = sizeof(int) * (size_t)N;
+    w.parent = take(nb); w.root = take(nb); w.comp_size = take(nb); w.visited = take(nb); w.claim = take(nb); w.worklist = take(nb);
+    w.scratch_node = take(nb); w.scratch_seed = take(nb); w.cl_size = take(nb); w.cl_start = take(nb);
+    w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
+    w.counters = take(sizeof(int) * 8);
+    w.scan_ws = take(ms3d_scan_workspace_bytes());
+    return off;
+}
+
+int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, const int *start_len, int N, int *cluster_idxs,
+            int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    counts[0] = counts[1] = 0;
+    if (N <= 0) {
+        MS3D_CHECK(hipMemsetAsync(cluster_offsets, 0, sizeof(int), stream));
+        return 0;
+    }
+    BfsWorkspace w;
+    if (carve(w, N, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
+    const int nb = ms3d_divup(N, 256);
+    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.counters);
+    MS3D_LAUNCH_CHECK();
+    bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+    MS3D_LAUNCH_CHECK();
+    bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size);
+    MS3D_LAUNCH_CHECK();
+    bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
+    MS3D_LAUNCH_CHECK();
+    bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                          w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                          w.scratch_seed, w.cl_size, w.cl_start);
+    MS3D_LAUNCH_CHECK();
+    bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
+    MS3D_LAUNCH_CHECK();
+    int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
+    if (rc) return rc;
+    rc = ms3d_exclusive_scan_i32(w.keep_size, w.out_off, N, w.counters + 4, w.scan_ws, stream);
+    if (rc) return rc;
+    bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
+                                           w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
+    MS3D_LAUNCH_CHECK();
+    int host[8];
+    MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+    MS3D_CHECK(hipStreamSynchronize(stream));
+    counts[0] = host[3];
+    counts[1] = host[4];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms3d_bfs_workspace_bytes(int N)
+{
+    BfsWorkspace w;
+    return carve(w, N > 0 ? N : 1, nullptr);
+}
+
+int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, const int *start_len, int N,
+                        int threshold, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
+                        size_t workspace_bytes, ms3d_stream_t stream)
+{
+    Thr thr{0, threshold, 0.f};
+    return bfs_run(thr, semantic_label, ball_query_idxs, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+                   workspace_bytes, (hipStream_t)stream);
+}
+
+int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_idxs, const int *start_len, int N,
+                        float threshold, int class_id, int *cluster_idxs, int *cluster_offsets, int *counts,
+                        void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
+{
+    const float m = class_numpoint_mean[class_id];  // bfs_cluster.cpp:113-120
+    Thr thr{1, 0, (m == -1.f) ? threshold : threshold * m};
+    return bfs_run(thr, nullptr, ball_query_idxs, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+                   workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// Segment (per-proposal) reductions for gfx950: sec_mean / sec_min / sec_max, roipool fp/bp,
+// global_avg_pool fp/bp.  Replaces the reference kernels in sec_mean/sec_mean.cu:12-86 and
+// roipool/roipool.cu:12-119, which launch min(C,32) threads (3 threads for the C=3 coordinate
+// case) and walk each segment serially from global memory.
+//
+// Design: one 64-lane wave per proposal.  Rows are pulled in 64-row tiles with one coalesced
+// wave load per channel group into LDS, so HBM/L2 traffic is S*C*4 bytes read once.
+//   * order-independent reductions (min / max / argmax) are done per lane over the tile and
+//     combined with a (value, row) tie-break that reproduces the serial "first extremum wins";
+//   * order-DEPENDENT float sums (sec_mean's divide-then-add chain, avg-pool's sum) keep the
+//     reference's exact serial order: lane c walks the staged tile row by row for channel c,
+//     so the result is bit-identical while the loads stay coalesced.
+#include "common.h"
+#include "../../include/minsu3d_hip.h"
+
+namespace {
+
+constexpr int TILE_ROWS = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_C_STAGE = 64;  // channels staged per pass
+
+enum SegOp { OP_MEAN = 0, OP_SUM_DIV = 1 };
+
+// sequential-order float accumulation (bit-exact with the reference's serial loops)
+template <int OP>
+__global__ __launch_bounds__(256) void seg_serial_sum_kernel(int P, int C, const float *__restrict__ inp,
+                                                             const int *__restrict__ offsets,
+                                                             float *__restrict__ out)
+{
+    __shared__ float tile[WAVES_PER_BLOCK][TILE_ROWS * MAX_C_STAGE];
+    const int w = wave_id(), l = lane_id();
+    float *t = tile[w];
+    for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
+        const int s = offsets[p], e = offsets[p + 1];
+        const float count = (float)(e - s);
+        for (int c0 = 0; c0 < C; c0 += MAX_C_STAGE) {
+            const int cw = min(MAX_C_STAGE, C - c0);
+            float acc = 0.f;
+            for (int r0 = s; r0 < e; r0 += TILE_ROWS) {
+                const int rows = min(TILE_ROWS, e - r0);
+                // stage rows*cw floats; consecutive lanes read consecutive addresses when cw == C
+                for (int q = l; q < rows * cw; q += 64) {
+                    const int r = q / cw, c = q - r * cw;
+                    float v = inp[(size_t)(r0 + r) * C + c0 + c];
+                    if (OP == OP_MEAN) v = v / count;  // sec_mean.cu:22 divides before adding
+                    t[r * cw + c] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave landed
+                if (l < cw)
+                    for (int r = 0; r < rows; r++) acc += t[r * cw + l];
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (l < cw) {
+                if (OP == OP_SUM_DIV) acc = acc / count;  // roipool.cu:78 sums then divides
+                out[(size_t)p * C + c0 + l] = acc;
+            }
+        }
+    }
+}
+
+// min / max (+argmax): lane-parallel over rows, then wave reduction with first-index tie-break
+template <bool IS_MAX, bool WITH_ARG>
+__global__ __launch_bounds__(256) void seg_extreme_kernel(int P, int C, const float *__restrict__ inp,
+                                                          const int *__restrict__ offsets,
+                                                          float *__restrict__ out, int *__restrict__ arg)
+{
+    const int w = wave_id(), l = lane_id();
+    const float ident = IS_MAX ? -INFINITY : INFINITY;  // the reference's +-1e50 is +-inf in f32
+    const bool pow2 = (C & (C - 1)) == 0 && C <= 64;
+    for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
+        const int s = offsets[p], e = offsets[p + 1];
+        if (pow2) {
+            // feature rows (C = 16/32): lanes = (row slot, channel) so a wave load is 256 contiguous bytes
+            const int c = l & (C - 1), rsub = l / C, rstep = 64 / C;
+            float best = ident;
+            int bi = -1;
+            for (int r = s + rsub; r < e; r += rstep) {
+                const float v = inp[(size_t)r * C + c];
+                if (IS_MAX ? (v > best) : (v < best)) {
+                    best = v;
+                    bi = r;
+                }
+            }
+            for (int d = 32; d >= C; d >>= 1) {
+                const float ov = __shfl_xor(best, d, 64);
+                const int oi = __shfl_xor(bi, d, 64);
+                const bool better = IS_MAX ? (ov > best) : (ov < best);
+                const bool tie = (ov == best) && (oi >= 0) && (bi < 0 || oi < bi);
+                if (better || tie) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            if (l < C) {
+                out[(size_t)p * C + c] = best;
+                if (WITH_ARG) arg[(size_t)p * C + c] = bi;
+            }
+            continue;
+        }
+        for (int c = 0; c < C; c++) {
+            float best = ident;
+            int bi = -1;
+            for (int r = s + l; r < e; r += 64) {  // ascending rows per lane: strict compare keeps the first
+                const float v = inp[(size_t)r * C + c];
+                if (IS_MAX ? (v > best) : (v < best)) {
+                    best = v;
+                    bi = r;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(best, d, 64);
+                const int oi = __shfl_xor(bi, d, 64);
+                const bool better = IS_MAX ? (ov > best) : (ov < best);
+                // equal values: the smaller row wins; bi == -1 marks "nothing selected yet"
+                const bool tie = (ov == best) && (oi >= 0) && (bi < 0 || oi < bi);
+                if (better || tie) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            if (l == 0) {
+                out[(size_t)p * C + c] = best;
+                if (WITH_ARG) arg[(size_t)p * C + c] = bi;
+            }
+        }
+    }
+}
+
+__global__ void roipool_bp_kernel(int P, int C, float *__restrict__ d_feats, const int *__restrict__ maxidx,
+                                  const float *__restrict__ d_out)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)P * C) return;
+    const int am = maxidx[t];
+    if (am < 0) return;  // empty proposal: the reference would index row -1 (roipool.cu:45-46)
+    const int c = (int)(t % C);
+    atomicAdd(&d_feats[(size_t)am * C + c], d_out[t]);
+}
+
+// proposals own disjoint row ranges, so every d_feats element receives exactly one addend
+__global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, float *__restrict__ d_feats,
+                                                          const int *__restrict__ offsets,
+                                                          const float *__restrict__ d_out)
+{
+    const int w = wave_id(), l = lane_id();
+    for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
+        const int s = offsets[p], e = offsets[p + 1];
+        const float n = (float)(e - s);
+        const long total = (long)(e - s) * C;
+        for (long q = l; q < total; q += 64) {
+            const int c = (int)(q % C);
+            d_feats[(size_t)s * C + q] += d_out[(size_t)p * C + c] / n;
+        }
+    }
+}
+
+inline int grid_for(int P) { return max(1, min(ms3d_divup(P, WAVES_PER_BLOCK), 4096)); }
+
+}  // namespace
+
+extern "C" {
+
+int ms3d_sec_mean(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    seg_serial_sum_kernel<OP_MEAN><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_sec_min(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    seg_extreme_kernel<false, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_sec_max(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    seg_extreme_kernel<true, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_roipool_fp(int P, int C, const float *feats, const int *offsets, float *out, int *maxidx,
+                    ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    seg_extreme_kernel<true, true><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out, maxidx);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_roipool_bp(int P, int C, float *d_feats, const int *offsets, const int *maxidx, const float *d_out,
+                    ms3d_stream_t stream)
+{
+    (void)offsets;
+    if (P <= 0 || C <= 0) return 0;
+    roipool_bp_kernel<<<ms3d_divup((long)P * C, 256), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, maxidx, d_out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_global_avg_pool_fp(int P, int C, const float *feats, const int *offsets, float *out,
+                            ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    seg_serial_sum_kernel<OP_SUM_DIV><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_global_avg_pool_bp(int P, int C, float *d_feats, const int *offsets, const float *d_out,
+                            ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0) return 0;
+    avg_pool_bp_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, offsets, d_out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+"""GPU parity: HIP grouping kernels (through the C ABI) vs the CPU oracle, the golden vectors made by
+the reference's own code, and -- when oracle/_ref travelled to this box -- the reference's own GPU
+kernels.  Integer/index outputs must be bit-exact; sec_mean / avg-pool float outputs too (same
+serial order)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from minsu3d_amd.backend import HipBackend
+    return HipBackend()
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda()
+
+
+def scene(rng, n, kind, B):
+    if kind == "surface":
+        xyz = rng.random((n, 3)) * np.array([2.0, 2.0, 0.04])
+    elif kind == "blobs":
+        c = rng.random((8, 3)) * 3
+        xyz = c[rng.integers(0, 8, n)] + rng.standard_normal((n, 3)) * 0.02
+    else:
+        xyz = rng.standard_normal((n, 3)) * 0.003
+    b = np.sort(rng.integers(0, B, n)).astype(np.uint8)
+    bo = np.concatenate([[0], np.cumsum(np.bincount(b, minlength=B))]).astype(np.int32)
+    return xyz.astype(np.float32), b, bo
+
+
+@pytest.mark.parametrize("kind,n,B,radius", [("surface", 20000, 3, 0.03), ("surface", 5000, 1, 0.06),
+                                             ("blobs", 6000, 2, 0.03), ("capped", 2500, 1, 0.03),
+                                             ("surface", 1, 1, 0.03), ("surface", 70, 2, 0.5)])
+def test_ballquery_vs_oracle(be, oracle, kind, n, B, radius):
+    rng = np.random.default_rng(n + B)
+    xyz, b, bo = scene(rng, n, kind, B)
+    want_idx, want_sl = oracle.ballquery_batch_p(xyz, b, bo, radius)
+    idx, sl = be.ballquery_batch_p(dev(xyz), dev(b), dev(bo), radius, 20)
+    assert np.array_equal(sl.cpu().numpy(), want_sl)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+
+
+def test_ballquery_empty(be):
+    idx, sl = be.ballquery_batch_p(torch.zeros((0, 3), device="cuda"), torch.zeros(0, dtype=torch.uint8, device="cuda"),
+                                   torch.zeros(2, dtype=torch.int32, device="cuda"), 0.03, 50)
+    assert idx.numel() == 0 and sl.shape == (0, 2)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_bfs_vs_golden(be, golden_dir, ci):
+    g = np.load(os.path.join(golden_dir, f"bfs_case{ci}.npz"))
+    # ball query on the device must rebuild the exact graph the reference BFS consumed
+    idx, sl = be.ballquery_batch_p(dev(g["xyz"]), dev(g["batch_idxs"]), dev(g["batch_offsets"]), float(g["radius"]), 50)
+    assert np.array_equal(idx.cpu().numpy(), g["ball_idx"]) and np.array_equal(sl.cpu().numpy(), g["start_len"])
+    a, b = be.pg_bfs_cluster(dev(g["sem"]), idx, sl, int(g["threshold"]))
+    assert np.array_equal(b.cpu().numpy(), g["pg_offsets"])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), g["pg_idxs"].reshape(-1, 2))
+    for k, cid in enumerate(g["sg_class_ids"]):
+        a, b = be.sg_bfs_cluster(g["sg_mean"].tolist(), idx, sl, float(g["sg_threshold"]), int(cid))
+        assert np.array_equal(b.cpu().numpy(), g[f"sg{k}_offsets"])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), g[f"sg{k}_idxs"].reshape(-1, 2))
+
+
+def test_bfs_kat(be, golden_dir):
+    g = np.load(os.path.join(golden_dir, "bfs_kat.npz"))
+    a, b = be.pg_bfs_cluster(dev(g["sem"]), dev(g["ball_idx"]), dev(g["start_len"]), int(g["threshold"]))
+    assert a.cpu().numpy().tolist() == g["pg_idxs"].tolist() and b.cpu().numpy().tolist() == g["pg_offsets"].tolist()
+
+
+@pytest.mark.parametrize("kind,n,B,radius,thr", [("surface", 30000, 2, 0.03, 50), ("surface", 8000, 1, 0.05, 5),
+                                                 ("blobs", 9000, 3, 0.03, 50), ("capped", 3000, 1, 0.03, 50),
+                                                 ("blobs", 4000, 1, 0.02, 1)])
+def test_bfs_vs_oracle(be, oracle, kind, n, B, radius, thr):
+    rng = np.random.default_rng(100 + n)
+    xyz, b, bo = scene(rng, n, kind, B)
+    idx, sl = oracle.ballquery_batch_p(xyz, b, bo, radius)
+    sem = rng.integers(2, 4, n).astype(np.int16)
+    if kind == "capped":
+        sem[:] = 2
+    want = oracle.pg_bfs_cluster(sem, idx, sl, thr)
+    a, o = be.pg_bfs_cluster(dev(sem), dev(idx), dev(sl), thr)
+    assert np.array_equal(o.cpu().numpy(), want[1])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    mean = [-1.0, 200.0, 1000.0]
+    for cid in range(3):
+        want = oracle.sg_bfs_cluster(mean, idx, sl, 0.05, cid)
+        a, o = be.sg_bfs_cluster(mean, dev(idx), dev(sl), 0.05, cid)
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+def test_bfs_deterministic(be, oracle):
+    rng = np.random.default_rng(9)
+    xyz, b, bo = scene(rng, 20000, "surface", 2)
+    idx, sl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
+    sem = rng.integers(0, 2, 20000).astype(np.int16)
+    r = [be.pg_bfs_cluster(dev(sem), dev(idx), dev(sl), 10) for _ in range(3)]
+    for k in (1, 2):
+        assert torch.equal(r[0][0], r[k][0]) and torch.equal(r[0][1], r[k][1])
+
+
+def _segments(rng, P, maxlen):
+    lens = rng.integers(0, maxlen, P)
+    lens[0] = maxlen * 3
+    if P > 3:
+        lens[3] = 0
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("C_", [3, 16, 32, 19, 100])
+def test_segment_ops_vs_oracle(be, oracle, C_):
+    rng = np.random.default_rng(C_)
+    off = _segments(rng, 300, 400)
+    S = int(off[-1])
+    x = rng.standard_normal((S, C_)).astype(np.float32)
+    x[5:40] = x[5]  # ties: first extremum must win
+    xd, od = dev(x), dev(off)
+    assert np.array_equal(be.sec_mean(xd, od).cpu().numpy(), oracle.sec_mean(x, off), equal_nan=True)
+    assert np.array_equal(be.sec_min(xd, od).cpu().numpy(), oracle.sec_min(x, off))
+    assert np.array_equal(be.sec_max(xd, od).cpu().numpy(), oracle.sec_max(x, off))
+    out, mi = be.roipool_fp(xd, od)
+    wout, wmi = oracle.roipool_fp(x, off)
+    assert np.array_equal(out.cpu().numpy(), wout) and np.array_equal(mi.cpu().numpy(), wmi)
+    assert np.array_equal(be.global_avg_pool_fp(xd, od).cpu().numpy(), oracle.global_avg_pool_fp(x, off),
+                          equal_nan=True)
+    # backward passes (drop the empty proposal: its argmax is -1)
+    keep = np.diff(off) > 0
+    off2 = np.concatenate([[0], np.cumsum(np.diff(off)[keep])]).astype(np.int32)
+    out2, mi2 = be.roipool_fp(xd, dev(off2))
+    g = rng.standard_normal(out2.shape).astype(np.float32)
+    got = be.roipool_bp(dev(g), dev(off2), mi2, S).cpu().numpy()
+    assert np.array_equal(got, oracle.roipool_bp(g, off2, mi2.cpu().numpy(), S))
+    got = be.global_avg_pool_bp(dev(g), dev(off2), S).cpu().numpy()
+    assert np.array_equal(got, oracle.global_avg_pool_bp(g, off2, S))
+
+
+@pytest.mark.parametrize("I", [1, 37, 300])
+def test_iou_family_vs_oracle(be, oracle, I):
+    rng = np.random.default_rng(I)
+    N = 40000
+    inst = rng.integers(-1, I, N).astype(np.int16)
+    pn = np.bincount(inst[inst >= 0], minlength=I).astype(np.int32)
+    off = _segments(rng, 120, 600)
+    S = int(off[-1])
+    pidx = rng.integers(0, N, S).astype(np.int32)
+    sig = rng.random(S).astype(np.float32)
+    cls = rng.integers(-1, 18, I).astype(np.int16)
+    args = (dev(pidx), dev(off), dev(inst), dev(pn))
+    iou = be.get_iou(*args)
+    assert np.array_equal(iou.cpu().numpy(), oracle.get_iou(pidx, off, inst, pn))
+    assert np.array_equal(be.get_mask_iou_on_cluster(*args).cpu().numpy(),
+                          oracle.get_mask_iou_on_cluster(pidx, off, inst, pn))
+    assert np.array_equal(be.get_mask_iou_on_pred(*args, dev(sig)).cpu().numpy(),
+                          oracle.get_mask_iou_on_pred(pidx, off, inst, pn, sig))
+    for thr in (0.0, 0.05, 0.5):
+        ml, mlm = be.get_mask_label(dev(pidx), dev(off), dev(inst), dev(cls), iou, -1, thr)
+        wml, wmlm = oracle.get_mask_label(pidx, off, inst, cls, iou.cpu().numpy(), -1, thr)
+        assert np.array_equal(ml.cpu().numpy(), wml) and np.array_equal(mlm.cpu().numpy(), wmlm)
+
+
+def test_full_size_properties(be):
+    """BASELINE-size inputs (4 scenes x ~90k foreground points): size-independent properties"""
+    rng = np.random.default_rng(1)
+    n, B = 360000, 4
+    xyz = (rng.random((n, 3)) * np.array([5.0, 4.0, 0.05])).astype(np.float32)
+    b = np.sort(rng.integers(0, B, n)).astype(np.uint8)
+    bo = np.concatenate([[0], np.cumsum(np.bincount(b, minlength=B))]).astype(np.int32)
+    idx, sl = be.ballquery_batch_p(dev(xyz), dev(b), dev(bo), 0.03, 50)
+    sl_c = sl.cpu().numpy(); idx_c = idx.cpu().numpy()
+    assert np.array_equal(sl_c[:, 0], np.concatenate([[0], np.cumsum(sl_c[:-1, 1])]))   # canonical starts
+    assert sl_c[:, 1].min() >= 1 and sl_c[:, 1].max() <= 1000                               # self is a neighbour
+    owner = np.repeat(np.arange(n), sl_c[:, 1])
+    assert np.array_equal(b[idx_c], b[owner])                                               # never crosses scenes
+    d = xyz[idx_c] - xyz[owner]
+    assert ((d * d).sum(1) < 0.03 ** 2 * 1.0001).all()
+    seg_sorted = np.diff(idx_c) > 0
+    boundary = np.zeros(idx_c.size - 1, bool); boundary[np.cumsum(sl_c[:, 1])[:-1] - 1] = True
+    assert (seg_sorted | boundary).all()                                                    # ascending lists
+    # symmetry (no list is capped here)
+    pairs = set(zip(owner[:200000].tolist(), idx_c[:200000].tolist()))
+    sub = [(j, i) for (i, j) in list(pairs)[:5000]]
+    full = {}
+    for (i, j) in sub:
+        lst = idx_c[sl_c[i, 0]:sl_c[i, 0] + sl_c[i, 1]]
+        assert j in lst
+    sem = rng.integers(2, 4, n).astype(np.int16)
+    a, o = be.pg_bfs_cluster(dev(sem), idx, sl, 50)
+    a = a.cpu().numpy(); o = o.cpu().numpy()
+    sizes = np.diff(o)
+    assert (sizes >= 50).all() and a.shape[0] == o[-1]
+    assert len(np.unique(a[:, 1])) == a.shape[0]                                            # a point is in <= 1 cluster
+    assert np.array_equal(a[:, 0], np.repeat(np.arange(sizes.size), sizes))
+    seeds = a[o[:-1], 1]
+    assert (np.diff(seeds) > 0).all()                                                       # clusters by ascending seed
+    mins = np.minimum.reduceat(a[:, 1], o[:-1])
+    assert np.array_equal(mins, seeds)                                                      # seed = smallest member
+    lab = sem[a[:, 1]]
+    assert np.array_equal(lab, np.repeat(sem[seeds], sizes))                                # label-pure clusters
+
+
+def test_reference_gpu_kernels_agree(be, oracle):
+    """the reference's OWN kernels (hipified build in oracle/_ref) on this GPU vs ours and the oracle"""
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref/libminsu3d_ref.so did not travel to this box")
+    rng = np.random.default_rng(11)
+    off = _segments(rng, 80, 300)
+    S = int(off[-1])
+    for C_ in (3, 16):
+        x = rng.standard_normal((S, C_)).astype(np.float32)
+        xd, od = dev(x), dev(off)
+        for name, ours in (("ref_sec_mean", be.sec_mean), ("ref_sec_min", be.sec_min), ("ref_sec_max", be.sec_max),
+                           ("ref_global_avg_pool_fp", be.global_avg_pool_fp)):
+            out = torch.zeros((off.size - 1, C_), device="cuda")
+            getattr(R, name)(off.size - 1, C_, C.c_void_p(xd.data_ptr()), C.c_void_p(od.data_ptr()),
+                             C.c_void_p(out.data_ptr()))
+            assert torch.equal(out, ours(xd, od)), name
+        out = torch.zeros((off.size - 1, C_), device="cuda"); mi = torch.zeros((off.size - 1, C_), dtype=torch.int32, device="cuda")
+        R.ref_roipool_fp(off.size - 1, C_, C.c_void_p(xd.data_ptr()), C.c_void_p(od.data_ptr()),
+                         C.c_void_p(out.data_ptr()), C.c_void_p(mi.data_ptr()))
+        o2, m2 = be.roipool_fp(xd, od)
+        assert torch.equal(out, o2) and torch.equal(mi, m2)
+    # IoU
+    I, N = 23, 5000
+    inst = rng.integers(-1, I, N).astype(np.int16); pn = np.bincount(inst[inst >= 0], minlength=I).astype(np.int32)
+    pidx = rng.integers(0, N, S).astype(np.int32); sig = rng.random(S).astype(np.float32)
+    d = [dev(pidx), dev(off), dev(inst), dev(pn)]
+    iou_ref = torch.zeros((off.size - 1, I), device="cuda")
+    R.ref_get_iou(I, off.size - 1, *[C.c_void_p(t.data_ptr()) for t in d], C.c_void_p(iou_ref.data_ptr()))
+    assert torch.equal(iou_ref, be.get_iou(*d))
+    iou_ref.zero_(); sd = dev(sig)
+    R.ref_get_mask_iou_on_pred(I, off.size - 1, *[C.c_void_p(t.data_ptr()) for t in d], C.c_void_p(iou_ref.data_ptr()),
+                               C.c_void_p(sd.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(iou_ref, be.get_mask_iou_on_pred(*d, sd))
+    # ball query: the reference's brute-force kernel, canonicalised (its start offsets are atomic-ordered)
+    n = 3000
+    xyz, b, bo = scene(rng, n, "surface", 2)
+    xd, bd, bod = dev(xyz), dev(b), dev(bo)
+    idx_r = torch.zeros(n * 60, dtype=torch.int32, device="cuda"); sl_r = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    R.ref_ballquery_batch_p.restype = C.c_int
+    tot = R.ref_ballquery_batch_p(n, 60, C.c_float(0.05), C.c_void_p(xd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                  C.c_void_p(bod.data_ptr()), C.c_void_p(idx_r.data_ptr()), C.c_void_p(sl_r.data_ptr()))
+    idx_o, sl_o = be.ballquery_batch_p(xd, bd, bod, 0.05, 60)
+    assert tot == idx_o.numel()
+    sl_r = sl_r.cpu().numpy(); idx_r = idx_r.cpu().numpy(); sl_o = sl_o.cpu().numpy(); idx_o = idx_o.cpu().numpy()
+    assert np.array_equal(sl_r[:, 1], sl_o[:, 1])
+    for i in range(n):
+        assert np.array_equal(idx_r[sl_r[i, 0]:sl_r[i, 0] + sl_r[i, 1]], idx_o[sl_o[i, 0]:sl_o[i, 0] + sl_o[i, 1]])
