@@ -91,6 +91,62 @@ int ms3d_get_mask_label(int nInstance, int nProposal, int ignored_label, float i
                         const float *proposals_iou, uint8_t *mask_label /*bool*/, uint8_t *mask_label_mask /*bool*/,
                         ms3d_stream_t stream);
 
+/* ======================================================================================
+ * Sparse-voxel engine: the MinkowskiEngine subset the reference backbone calls.  MinkowskiEngine is a
+ * third-party dependency of the reference (un-pinned, README.md:45,73) and is NOT under /root/reference;
+ * the entry points below are what a binding for the reference's call sites would need:
+ *   ME.utils.sparse_quantize      data/dataset/general_dataset.py:159-163, model/general_model.py:187-189
+ *   ME.SparseTensor / coordinate manager + kernel maps   model/module/backbone.py:38, common.py:69,77
+ *   ME.MinkowskiConvolution / ConvolutionTranspose fwd+bwd  model/module/common.py:31,37,40,69,77
+ *   ME.MinkowskiBatchNorm / MinkowskiReLU (fused into the conv gather)  common.py:35-39,67-68,75-76
+ * Kernel maps are output-stationary neighbour tables stored offset-major: nbr[k * V_out + i] = input row
+ * feeding output row i through kernel offset k, or -1.
+ * ====================================================================================== */
+size_t ms3d_coord_workspace_bytes(int n);
+/* first-occurrence unique of int32 rows [n,4] (b,x,y,z): unique_idx[u] ascending, inverse[i] = u;
+ * *n_unique -> [host].  unique_idx may be NULL. */
+int ms3d_sparse_quantize(const int *coords, int n, int *unique_idx, int *inverse, int *n_unique /*[host]*/,
+                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
+/* submanifold 3x3x3 table nbr[27][V]; offset k = ix + 3*iy + 9*iz <-> (ix-1, iy-1, iz-1)*tensor_stride */
+int ms3d_kmap_k3(const int *coords, int V, int tensor_stride, int *nbr, void *workspace, size_t workspace_bytes,
+                 ms3d_stream_t stream);
+/* stride-2 coarse coordinate set (first-occurrence order), parent row and in-cell offset of every fine row */
+int ms3d_downsample(const int *coords, int V, int tensor_stride, int *out_coords, int *parent, int *koff,
+                    int *n_coarse /*[host]*/, void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
+/* k2 s2 tables: nbr_down[8][Vc] (conv) and nbr_up[8][Vf] (transposed conv) */
+int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_down, int *nbr_up,
+                 ms3d_stream_t stream);
+
+/* weights W[K][Cin][Cout] -> MFMA-fragment order.  transpose=1 (+mirror=1 for k3) gives the backward-data
+ * operator: Weff[k] = W[mirror ? K-1-k : k]^T with Cin_eff = Cout, Cout_eff = Cin. */
+size_t ms3d_spconv_wf_floats(int K, int Cin_eff, int Cout_eff);
+int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, int transpose, int mirror, float *wf,
+                             ms3d_stream_t stream);
+/* out[i,:] = sum_k act(in[nbr[k][i],:]) @ Weff[k] (+ residual); act = optional x*pre_scale+pre_shift (+ReLU).
+ * With bn_x != NULL the epilogue is the backward of a fused BN+ReLU: out = dz = acc * [bn_x*bn_scale+bn_shift > 0]
+ * and bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block sums of dz and dz*xhat. */
+int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout);
+int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
+                        float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
+                        const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
+                        const float *bn_mean, const float *bn_invstd, float *bn_partial, ms3d_stream_t stream);
+/* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:]  (dW zeroed here, float atomics across row chunks) */
+int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
+                                int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
+                                ms3d_stream_t stream);
+/* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */
+int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,
+                  float *running_mean, float *running_var, float *mean, float *invstd, float *scale, float *shift,
+                  float *partial_ws, int partial_rows, ms3d_stream_t stream);
+int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float *shift, int relu, float *y,
+                  ms3d_stream_t stream);
+int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream);
+int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
+                      const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream);
+int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const float *scale, const float *shift,
+                        const float *mean, const float *invstd, int relu, float *dz, float *partial_ws,
+                        int partial_rows, int *nparts_out /*[host]*/, ms3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

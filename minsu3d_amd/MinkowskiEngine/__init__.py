@@ -1,0 +1,12 @@
+"""The MinkowskiEngine subset the reference models import (`import MinkowskiEngine as ME`), served by the
+gfx950 sparse-voxel engine.  Exactly the 9 symbols the reference uses:
+
+    SparseTensor, MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm, MinkowskiReLU,
+    cat, utils.sparse_quantize, utils.sparse_collate  (+ tensor attributes .features/.F, .coordinates/.C)
+
+Module/parameter names match ME so reference state_dicts keep their keys (`kernel`, `bn.weight`, ...).
+"""
+from . import utils  # noqa: F401
+from .tensor import SparseTensor, CoordinateManager, cat  # noqa: F401
+from .modules import (MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,  # noqa: F401
+                      MinkowskiReLU)

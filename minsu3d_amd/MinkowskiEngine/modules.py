@@ -1,0 +1,115 @@
+"""nn.Module surface of the MinkowskiEngine subset (same constructor arguments, parameter names and init as ME
+v0.5.4): `kernel` of shape (K, in, out) -- (in, out) for kernel_size 1 -- no bias,
+uniform(-1/sqrt(in*K), +1/sqrt(in*K)); MinkowskiBatchNorm wraps `self.bn = nn.BatchNorm1d`."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..backend import get_backend
+from . import functional as Fn
+from .tensor import SparseTensor
+
+
+class _ConvBase(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        assert dimension == 3 and dilation == 1 and not bias, "only what the reference uses is implemented"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        K = kernel_size ** 3
+        self.kernel_volume = K
+        shape = (in_channels, out_channels) if (kernel_size == 1 and stride == 1) else (K, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        s = 1.0 / math.sqrt(in_channels * K)
+        with torch.no_grad():
+            self.kernel.uniform_(-s, s)
+
+    def extra_repr(self):
+        return f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
+
+
+class MinkowskiConvolution(_ConvBase):
+    """k3 s1 (submanifold, output coords = input coords), k2 s2 (downsample) and k1 s1"""
+
+    def forward(self, x: SparseTensor):
+        cm, ts = x.coordinate_manager, x.tensor_stride
+        cin, cout = self.in_channels, self.out_channels
+        if self.kernel_size == 3 and self.stride == 1:
+            nbr = cm.k3(ts)
+            V = cm.size(ts)
+            spec = Fn.ConvSpec(nbr, nbr, V, V, 27, cin, cout, True)
+            out_ts = ts
+        elif self.kernel_size == 2 and self.stride == 2:
+            down, up = cm.k2(ts)
+            spec = Fn.ConvSpec(down, up, cm.size(ts), cm.size(2 * ts), 8, cin, cout, False)
+            out_ts = 2 * ts
+        elif self.kernel_size == 1 and self.stride == 1:
+            ident = cm.identity(ts)
+            V = cm.size(ts)
+            spec = Fn.ConvSpec(ident, ident, V, V, 1, cin, cout, False)
+            out_ts = ts
+        else:
+            raise NotImplementedError((self.kernel_size, self.stride))
+        y = Fn.conv(x._F, self.kernel, spec, x._pending)
+        return x._like(y, tensor_stride=out_ts)
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    """k2 s2 transposed: output lives on the cached coordinate set of stride ts/2 (the encoder's)"""
+
+    def forward(self, x: SparseTensor):
+        cm, ts = x.coordinate_manager, x.tensor_stride
+        assert self.kernel_size == 2 and self.stride == 2 and ts % 2 == 0
+        fine = ts // 2
+        down, up = cm.k2(fine)  # cached by the encoder's strided convolution
+        spec = Fn.ConvSpec(up, down, cm.size(ts), cm.size(fine), 8, self.in_channels, self.out_channels, False)
+        y = Fn.conv(x._F, self.kernel, spec, x._pending)
+        return x._like(y, tensor_stride=fine)
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm1d over the rows of .F.  Statistics are reduced by a HIP kernel now; normalisation itself is
+    deferred to the consumer (see tensor.py)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, x: SparseTensor):
+        bn = self.bn
+        feats = x.features  # materialise anything pending in front of this BN
+        use_batch = self.training or not bn.track_running_stats
+        if use_batch:
+            with torch.no_grad():
+                rm = bn.running_mean if (self.training and bn.track_running_stats) else None
+                rv = bn.running_var if rm is not None else None
+                mean, invstd, scale, shift = get_backend().bn_stats(
+                    feats.detach(), bn.eps, 0.1 if bn.momentum is None else bn.momentum,
+                    bn.weight.detach() if bn.affine else None, bn.bias.detach() if bn.affine else None, rm, rv)
+                if rm is not None:
+                    bn.num_batches_tracked += 1
+        else:
+            with torch.no_grad():
+                invstd = torch.rsqrt(bn.running_var + bn.eps)
+                mean = bn.running_mean
+                scale = bn.weight * invstd if bn.affine else invstd
+                shift = (bn.bias if bn.affine else 0) - mean * scale
+        pending = dict(gamma=bn.weight if bn.affine else torch.ones_like(scale),
+                       beta=bn.bias if bn.affine else torch.zeros_like(scale), mean=mean.contiguous(),
+                       invstd=invstd.contiguous(), scale=scale.contiguous(), shift=shift.contiguous(), relu=False,
+                       training=use_batch)
+        return x._like(feats, pending=pending)
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x: SparseTensor):
+        if x._pending is not None and x._pending.get("gamma") is not None and not x._pending["relu"]:
+            p = dict(x._pending)
+            p["relu"] = True
+            return x._like(x._F, pending=p)
+        return x._like(torch.relu(x.features))

@@ -1,0 +1,104 @@
+"""SparseTensor + coordinate manager.
+
+A SparseTensor is (features [V, C], coordinate manager, tensor stride).  Row order of the input coordinates is
+preserved (the reference indexes the U-Net output with the dataset's voxel_point_map, backbone.py:40).
+
+BatchNorm / ReLU are LAZY: `MinkowskiBatchNorm` computes the batch statistics with a HIP reduction and returns
+a tensor that only records (scale, shift[, relu]); the following convolution applies them while gathering its
+input rows, so `Sequential(BN, ReLU, Conv)` is one gather kernel and never materialises the normalised
+activations.  Touching `.features` of such a tensor materialises it (one elementwise kernel).
+"""
+import torch
+
+from ..backend import get_backend
+from . import functional as Fn
+
+
+class CoordinateManager:
+    """coordinates per tensor stride and kernel maps per (stride, kind), built once and shared by every
+    convolution of a level and by the backward pass (ME's coordinate manager does the same caching)."""
+
+    def __init__(self, coordinates):
+        assert coordinates.dtype == torch.int32 and coordinates.size(1) == 4
+        self.coords = {1: coordinates.contiguous()}
+        self._k3 = {}
+        self._k2 = {}       # fine stride -> (nbr_down [8,Vc], nbr_up [8,Vf])
+        self._ident = {}
+
+    def k3(self, ts):
+        if ts not in self._k3:
+            self._k3[ts] = get_backend().kmap_k3(self.coords[ts], ts)
+        return self._k3[ts]
+
+    def k2(self, ts):
+        """stride-2 map from tensor stride ts to 2*ts; creates the coarse coordinate set on first use"""
+        if ts not in self._k2:
+            be = get_backend()
+            oc, parent, koff = be.downsample(self.coords[ts], ts)
+            if 2 * ts not in self.coords:
+                self.coords[2 * ts] = oc.contiguous()
+            self._k2[ts] = be.kmap_k2(parent, koff, oc.size(0))
+        return self._k2[ts]
+
+    def identity(self, ts):
+        if ts not in self._ident:
+            V = self.coords[ts].size(0)
+            self._ident[ts] = torch.arange(V, dtype=torch.int32, device=self.coords[ts].device).view(1, V)
+        return self._ident[ts]
+
+    def size(self, ts):
+        return self.coords[ts].size(0)
+
+
+class SparseTensor:
+    def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1,
+                 _pending=None):
+        if coordinate_manager is None:
+            if device is not None:
+                features, coordinates = features.to(device), coordinates.to(device)
+            coordinate_manager = CoordinateManager(coordinates.to(torch.int32))
+        self._F = features
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = tensor_stride
+        self._pending = _pending  # None or dict(scale, shift, relu, bn ctx) not yet applied to _F
+
+    # ---- ME attribute surface
+    @property
+    def features(self):
+        self._materialize()
+        return self._F
+
+    F = features
+
+    @property
+    def coordinates(self):
+        return self.coordinate_manager.coords[self.tensor_stride]
+
+    C = coordinates
+
+    @property
+    def device(self):
+        return self._F.device
+
+    def _materialize(self):
+        if self._pending is not None:
+            self._F = Fn.bn_act(self._F, self._pending)
+            self._pending = None
+
+    def _like(self, features, pending=None, tensor_stride=None):
+        return SparseTensor(features, coordinate_manager=self.coordinate_manager,
+                            tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride,
+                            _pending=pending)
+
+    def __iadd__(self, other):      # `x += identity` (common.py:48)
+        self._materialize()
+        self._F = self._F + other.features
+        return self
+
+    def __add__(self, other):
+        return self._like(self.features + other.features)
+
+
+def cat(*tensors):
+    """ME.cat: channel concat of tensors sharing one coordinate map (common.py:93)"""
+    return tensors[0]._like(torch.cat([t.features for t in tensors], dim=1))

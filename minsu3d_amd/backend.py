@@ -184,3 +184,160 @@ class HipBackend:
                                           _lib.stream_handle())
         _lib.check(rc, "ms3d_get_mask_label")
         return ml, mlm
+
+
+# ---------------------------------------------------------------------------------------------
+# Sparse-voxel engine methods (coordinate maps, fused BN/ReLU/conv kernels).  Kept in a mixin-style
+# block so the oracle-backed test double (oracle/oracle_backend.py) can mirror the same surface.
+# ---------------------------------------------------------------------------------------------
+def _f32(t):
+    return None if t is None else t.contiguous()
+
+
+class _HipEngine:
+    PARTIAL_ROWS = 1024
+
+    # ---- coordinates
+    def _cws(self, n, dev):
+        return self.ws.get("coord", self.lib.ms3d_coord_workspace_bytes(max(n, 1)), dev)
+
+    def sparse_quantize(self, coords):
+        coords = self._dev(coords)
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.size(1) == 4
+        n, dev = coords.size(0), coords.device
+        uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ws = self._cws(n, dev)
+        nu = C.c_int(0)
+        _lib.check(self.lib.ms3d_sparse_quantize(_lib.ptr(coords), n, _lib.ptr(uniq), _lib.ptr(inv), C.byref(nu),
+                                                 _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()),
+                   "ms3d_sparse_quantize")
+        return uniq[:nu.value], inv[:n]
+
+    def kmap_k3(self, coords, ts):
+        coords = self._dev(coords)
+        V, dev = coords.size(0), coords.device
+        nbr = torch.empty((27, max(V, 1)), dtype=torch.int32, device=dev)
+        ws = self._cws(V, dev)
+        _lib.check(self.lib.ms3d_kmap_k3(_lib.ptr(coords), V, int(ts), _lib.ptr(nbr), _lib.ptr(ws),
+                                         C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_kmap_k3")
+        return nbr
+
+    def downsample(self, coords, ts):
+        coords = self._dev(coords)
+        V, dev = coords.size(0), coords.device
+        oc = torch.empty((max(V, 1), 4), dtype=torch.int32, device=dev)
+        parent = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+        koff = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+        ws = self._cws(V, dev)
+        nc = C.c_int(0)
+        _lib.check(self.lib.ms3d_downsample(_lib.ptr(coords), V, int(ts), _lib.ptr(oc), _lib.ptr(parent),
+                                            _lib.ptr(koff), C.byref(nc), _lib.ptr(ws), C.c_size_t(ws.numel()),
+                                            _lib.stream_handle()), "ms3d_downsample")
+        return oc[:nc.value], parent[:V], koff[:V]
+
+    def kmap_k2(self, parent, koff, vc):
+        vf, dev = parent.numel(), parent.device
+        down = torch.empty((8, max(vc, 1)), dtype=torch.int32, device=dev)
+        up = torch.empty((8, max(vf, 1)), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.ms3d_kmap_k2(_lib.ptr(parent), _lib.ptr(koff), vf, int(vc), _lib.ptr(down), _lib.ptr(up),
+                                         _lib.stream_handle()), "ms3d_kmap_k2")
+        return down, up
+
+    # ---- convolution
+    def prep_weights(self, W, K, cin_e, cout_e, transpose=False, mirror=False):
+        W = self._dev(W)
+        self.lib.ms3d_spconv_wf_floats.restype = C.c_size_t
+        nfl = self.lib.ms3d_spconv_wf_floats(int(K), int(cin_e), int(cout_e))
+        wf = torch.empty(nfl, dtype=torch.float32, device=W.device)
+        _lib.check(self.lib.ms3d_spconv_prep_weights(_lib.ptr(W), int(K), int(cin_e), int(cout_e), int(transpose),
+                                                     int(mirror), _lib.ptr(wf), _lib.stream_handle()),
+                   "ms3d_spconv_prep_weights")
+        return wf
+
+    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None):
+        """out = sum_k act(x[nbr[k]]) @ Weff[k] (+ residual).  pre = (scale, shift) fuses BN(+ReLU) on the input.
+        bn_bwd = (bn_x, scale, shift, mean, invstd): backward-data epilogue of a fused BN+ReLU; returns (dz, s1s2)."""
+        x = self._dev(x)
+        out = torch.empty((vout, cout), dtype=torch.float32, device=x.device)
+        ps, pb = (pre if pre is not None else (None, None))
+        partial = None
+        bnargs = [None] * 5
+        if bn_bwd is not None:
+            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout))
+            partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
+            bnargs = [_f32(t) for t in bn_bwd]
+        _lib.check(self.lib.ms3d_spconv_forward(
+            _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
+            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
+            *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), _lib.stream_handle()), "ms3d_spconv_forward")
+        if bn_bwd is None:
+            return out
+        s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.ms3d_reduce_partials(_lib.ptr(partial), partial.size(0), 2 * cout, _lib.ptr(s1s2),
+                                                 _lib.stream_handle()), "ms3d_reduce_partials")
+        return out, s1s2
+
+    def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):
+        x = self._dev(x); dout = self._dev(dout)
+        dW = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
+        ps, pb = (pre if pre is not None else (None, None))
+        _lib.check(self.lib.ms3d_spconv_backward_weight(
+            _lib.ptr(x), _lib.ptr(dout), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(dW),
+            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.stream_handle()),
+            "ms3d_spconv_backward_weight")
+        return dW
+
+    # ---- batch norm pieces
+    def _partial_ws(self, C_, dev):
+        return self.ws.get("bnpart", self.PARTIAL_ROWS * 2 * C_ * 4, dev)
+
+    def bn_stats(self, x, eps, momentum, gamma, beta, running_mean, running_var):
+        """training-mode statistics -> (mean, invstd, scale, shift); running stats updated in place"""
+        x = self._dev(x)
+        V, C_ = x.shape
+        dev = x.device
+        outs = torch.empty((4, C_), dtype=torch.float32, device=dev)
+        ws = self._partial_ws(C_, dev)
+        _lib.check(self.lib.ms3d_bn_stats(_lib.ptr(x), C.c_long(V), int(C_), C.c_float(eps), C.c_float(momentum),
+                                          _lib.ptr(_f32(gamma)), _lib.ptr(_f32(beta)), _lib.ptr(running_mean),
+                                          _lib.ptr(running_var), _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
+                                          _lib.ptr(outs[3]), _lib.ptr(ws), self.PARTIAL_ROWS, _lib.stream_handle()),
+                   "ms3d_bn_stats")
+        return outs[0], outs[1], outs[2], outs[3]
+
+    def bn_apply(self, x, scale, shift, relu):
+        x = self._dev(x)
+        y = torch.empty_like(x)
+        _lib.check(self.lib.ms3d_bn_apply(_lib.ptr(x), C.c_long(x.size(0)), int(x.size(1)), _lib.ptr(scale),
+                                          _lib.ptr(shift), int(bool(relu)), _lib.ptr(y), _lib.stream_handle()),
+                   "ms3d_bn_apply")
+        return y
+
+    def bn_bwd_reduce(self, dy, x, scale, shift, mean, invstd, relu):
+        """stand-alone BN(+ReLU) backward stage 1 -> (dz, s1s2)"""
+        dy = self._dev(dy); x = self._dev(x)
+        V, C_ = x.shape
+        dz = torch.empty_like(x)
+        ws = self._partial_ws(C_, x.device)
+        nparts = C.c_int(0)
+        _lib.check(self.lib.ms3d_bn_bwd_partial(_lib.ptr(dy), _lib.ptr(x), C.c_long(V), int(C_), _lib.ptr(scale),
+                                                _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), int(bool(relu)),
+                                                _lib.ptr(dz), _lib.ptr(ws), self.PARTIAL_ROWS, C.byref(nparts),
+                                                _lib.stream_handle()), "ms3d_bn_bwd_partial")
+        s1s2 = torch.empty((2, C_), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.ms3d_reduce_partials(_lib.ptr(ws), nparts.value, 2 * C_, _lib.ptr(s1s2),
+                                                 _lib.stream_handle()), "ms3d_reduce_partials")
+        return dz, s1s2
+
+    def bn_bwd_apply(self, dz, x, scale, mean, invstd, s1s2):
+        dx = torch.empty_like(dz)
+        _lib.check(self.lib.ms3d_bn_bwd_apply(_lib.ptr(dz), _lib.ptr(x), C.c_long(x.size(0)), int(x.size(1)),
+                                              _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(s1s2),
+                                              _lib.ptr(dx), _lib.stream_handle()), "ms3d_bn_bwd_apply")
+        return dx
+
+
+for _name, _fn in list(vars(_HipEngine).items()):
+    if not _name.startswith("__"):
+        setattr(HipBackend, _name, _fn)

@@ -1,0 +1,273 @@
+// Coordinate engine for the sparse-voxel backbone (the part of MinkowskiEngine's coordinate manager the
+// reference relies on: call sites model/module/backbone.py:38, common.py:69,77, general_model.py:187-191,
+// data/dataset/general_dataset.py:159-163).
+//
+//   * 64-bit key (batch:19 | x:15 | y:15 | z:15, biased) in an open-addressing table in HBM
+//   * sparse_quantize / stride-2 downsample: value = atomicMin(row) so the FIRST row of every
+//     coordinate is its representative and unique rows come out in first-occurrence order
+//     (flag -> exclusive scan -> rank); deterministic, no sort
+//   * kernel maps as OUTPUT-STATIONARY neighbour tables, stored offset-major  nbr[k][V_out]  so that the
+//     16 output rows a wave owns read 64 contiguous bytes per offset:
+//       k3 s1 : nbr[k][i] = row at c_i + o_k*ts            (k = ix + 3*iy + 9*iz, x fastest)
+//       k2 s2 : down[k][p] = child of coarse row p at offset k;  up[k][f] = (k == koff[f]) ? parent[f] : -1
+#include "common.h"
+#include "scan.h"
+#include "../../include/minsu3d_hip.h"
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+__device__ __forceinline__ bool in_range(int v) { return v >= -16384 && v < 16384; }
+__device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int z)
+{
+    return ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)(unsigned)((x + 16384) & 0x7FFF) << 30) |
+           ((unsigned long long)(unsigned)((y + 16384) & 0x7FFF) << 15) | (unsigned long long)(unsigned)((z + 16384) & 0x7FFF);
+}
+__device__ __forceinline__ int floor_div(int v, int d) { return (v >= 0) ? (v / d) : -((-v + d - 1) / d); }
+
+__global__ void table_clear_kernel(unsigned long long *keys, int *vals, int H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < H) {
+        keys[t] = EMPTY_KEY;
+        vals[t] = 0x7fffffff;
+    }
+}
+
+// insert (optionally the stride-`q` floored coordinate) with value = min row; slot_of_row remembers the slot
+__global__ void table_insert_kernel(const int *__restrict__ coords, int n, int q, unsigned long long *keys, int *vals,
+                                    unsigned mask, int *__restrict__ slot_of_row)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    int x = c.y, y = c.z, z = c.w;
+    if (q > 1) {
+        x = floor_div(x, q) * q;
+        y = floor_div(y, q) * q;
+        z = floor_div(z, q) * q;
+    }
+    const unsigned long long key = pack_key(c.x, x, y, z);
+    unsigned slot = (unsigned)mix64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&keys[slot], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&vals[slot], i);
+    if (slot_of_row) slot_of_row[i] = (int)slot;
+}
+
+__global__ void first_flag_kernel(int n, const int *__restrict__ slot_of_row, const int *__restrict__ vals,
+                                  int *__restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (vals[slot_of_row[i]] == i) ? 1 : 0;
+}
+
+// unique_idx[rank[i]] = i for representatives; inverse[i] = rank[representative(i)]
+__global__ void unique_emit_kernel(int n, const int *__restrict__ slot_of_row, const int *__restrict__ vals,
+                                   const int *__restrict__ rank, int *__restrict__ unique_idx,
+                                   int *__restrict__ inverse)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int rep = vals[slot_of_row[i]];
+    if (rep == i && unique_idx) unique_idx[rank[i]] = i;
+    inverse[i] = rank[rep];
+}
+
+// coarse coords + in-cell offset index for the stride-2 map
+__global__ void downsample_emit_kernel(int n, int ts, const int *__restrict__ coords, const int *__restrict__ slot_of_row,
+                                       const int *__restrict__ vals, const int *__restrict__ rank,
+                                       int *__restrict__ out_coords, int *__restrict__ parent, int *__restrict__ koff)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const int t2 = ts * 2;
+    const int qx = floor_div(c.y, t2) * t2, qy = floor_div(c.z, t2) * t2, qz = floor_div(c.w, t2) * t2;
+    const int rep = vals[slot_of_row[i]];
+    const int p = rank[rep];
+    parent[i] = p;
+    koff[i] = (c.y - qx) / ts + 2 * ((c.z - qy) / ts) + 4 * ((c.w - qz) / ts);
+    if (rep == i) reinterpret_cast<int4 *>(out_coords)[p] = make_int4(c.x, qx, qy, qz);
+}
+
+__device__ __forceinline__ int table_lookup(const unsigned long long *__restrict__ keys, const int *__restrict__ vals,
+                                            unsigned mask, unsigned long long key)
+{
+    unsigned slot = (unsigned)mix64(key) & mask;
+    for (;;) {
+        const unsigned long long k = keys[slot];
+        if (k == key) return vals[slot];
+        if (k == EMPTY_KEY) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// one thread per (offset, row): writes nbr[k][i]; consecutive threads -> consecutive rows (coalesced stores)
+__global__ void kmap_k3_kernel(const int *__restrict__ coords, int V, int ts, const unsigned long long *__restrict__ keys,
+                               const int *__restrict__ vals, unsigned mask, int *__restrict__ nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= V) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const int x = c.y + (k % 3 - 1) * ts, y = c.z + ((k / 3) % 3 - 1) * ts, z = c.w + (k / 9 - 1) * ts;
+    int r = -1;
+    if (k == 13)
+        r = i;
+    else if (in_range(x) && in_range(y) && in_range(z))
+        r = table_lookup(keys, vals, mask, pack_key(c.x, x, y, z));
+    nbr[(size_t)k * V + i] = r;
+}
+
+__global__ void fill_minus1_kernel(int *p, long n)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = -1;
+}
+__global__ void kmap_k2_kernel(const int *__restrict__ parent, const int *__restrict__ koff, int Vf, int Vc,
+                               int *__restrict__ nbr_down, int *__restrict__ nbr_up)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= Vf) return;
+    const int p = parent[f], k = koff[f];
+    nbr_down[(size_t)k * Vc + p] = f;
+    nbr_up[(size_t)k * Vf + f] = p;
+}
+
+struct CoordWs {
+    unsigned long long *keys;
+    int *vals, *slot_of_row, *flag, *rank, *total;
+    void *scan_ws;
+    int H;
+};
+int table_size(int n)
+{
+    int H = 1024;
+    while (H < 2 * n) H <<= 1;
+    return H;
+}
+size_t carve(CoordWs &w, int n, void *base)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *r = base ? (void *)((char *)base + off) : nullptr;
+        off += ms3d_align(bytes);
+        return r;
+    };
+    w.H = table_size(n);
+    w.keys = (unsigned long long *)take(sizeof(unsigned long long) * w.H);
+    w.vals = (int *)take(sizeof(int) * w.H);
+    w.slot_of_row = (int *)take(sizeof(int) * n);
+    w.flag = (int *)take(sizeof(int) * n);
+    w.rank = (int *)take(sizeof(int) * n);
+    w.total = (int *)take(sizeof(int) * 2);
+    w.scan_ws = take(ms3d_scan_workspace_bytes());
+    return off;
+}
+
+int build_table(CoordWs &w, const int *coords, int n, int q, hipStream_t stream)
+{
+    table_clear_kernel<<<ms3d_divup(w.H, 256), 256, 0, stream>>>(w.keys, w.vals, w.H);
+    MS3D_LAUNCH_CHECK();
+    table_insert_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(coords, n, q, w.keys, w.vals, (unsigned)w.H - 1u,
+                                                              w.slot_of_row);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int rank_first(CoordWs &w, int n, int *count_host, hipStream_t stream)
+{
+    first_flag_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(n, w.slot_of_row, w.vals, w.flag);
+    MS3D_LAUNCH_CHECK();
+    int rc = ms3d_exclusive_scan_i32(w.flag, w.rank, n, w.total, w.scan_ws, stream);
+    if (rc) return rc;
+    if (count_host) {
+        MS3D_CHECK(hipMemcpyAsync(count_host, w.total, sizeof(int), hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms3d_coord_workspace_bytes(int n)
+{
+    CoordWs w;
+    return carve(w, n > 0 ? n : 1, nullptr);
+}
+
+int ms3d_sparse_quantize(const int *coords, int n, int *unique_idx, int *inverse, int *n_unique, void *workspace,
+                         size_t workspace_bytes, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    *n_unique = 0;
+    if (n <= 0) return 0;
+    CoordWs w;
+    if (carve(w, n, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
+    int rc = build_table(w, coords, n, 1, stream);
+    if (rc) return rc;
+    rc = rank_first(w, n, n_unique, stream);
+    if (rc) return rc;
+    unique_emit_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(n, w.slot_of_row, w.vals, w.rank, unique_idx, inverse);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_kmap_k3(const int *coords, int V, int tensor_stride, int *nbr, void *workspace, size_t workspace_bytes,
+                 ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V <= 0) return 0;
+    CoordWs w;
+    if (carve(w, V, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
+    int rc = build_table(w, coords, V, 1, stream);
+    if (rc) return rc;
+    dim3 grid(ms3d_divup(V, 256), 27);
+    kmap_k3_kernel<<<grid, 256, 0, stream>>>(coords, V, tensor_stride, w.keys, w.vals, (unsigned)w.H - 1u, nbr);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_downsample(const int *coords, int V, int tensor_stride, int *out_coords, int *parent, int *koff, int *n_coarse,
+                    void *workspace, size_t workspace_bytes, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    *n_coarse = 0;
+    if (V <= 0) return 0;
+    CoordWs w;
+    if (carve(w, V, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
+    int rc = build_table(w, coords, V, tensor_stride * 2, stream);
+    if (rc) return rc;
+    rc = rank_first(w, V, n_coarse, stream);
+    if (rc) return rc;
+    downsample_emit_kernel<<<ms3d_divup(V, 256), 256, 0, stream>>>(V, tensor_stride, coords, w.slot_of_row, w.vals, w.rank,
+                                                                 out_coords, parent, koff);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_down, int *nbr_up, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Vf <= 0) return 0;
+    fill_minus1_kernel<<<ms3d_divup((long)Vc * 8, 256), 256, 0, stream>>>(nbr_down, (long)Vc * 8);
+    MS3D_LAUNCH_CHECK();
+    fill_minus1_kernel<<<ms3d_divup((long)Vf * 8, 256), 256, 0, stream>>>(nbr_up, (long)Vf * 8);
+    MS3D_LAUNCH_CHECK();
+    kmap_k2_kernel<<<ms3d_divup(Vf, 256), 256, 0, stream>>>(parent, koff, Vf, Vc, nbr_down, nbr_up);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,658 @@
+// Sparse 3-D convolution for gfx950 (CDNA4), the MinkowskiEngine arithmetic the reference backbone runs
+// (call sites model/module/common.py:31,37,40,69,77, backbone.py:14; semantics SURVEY Appendix A.4/A.5/A.9).
+//
+// One kernel family serves k3 s1 (K = 27), k2 s2 (K = 8), transposed k2 s2 (K = 8, one-hot table) and
+// k1 (K = 1, identity table), forward and backward-data, because every case is
+//
+//        out[i, :] = sum_k  act(in[nbr[k][i], :]) @ Weff[k]          (nbr = -1 -> no contribution)
+//
+// OUTPUT-STATIONARY: a 64-lane wave owns 16 output rows and all (<= 8 x 16) output columns, gathers the
+// neighbour rows offset by offset and accumulates in registers; each output row is written exactly once,
+// coalesced, without atomics (ME's gather-GEMM-scatter does one atomic scatter per pair).
+//   * gather : lane (i = l & 15, q = l >> 4) reads 16 B = channels 16*ch + 4*q .. +3 of row nbr[k][row0+i];
+//              the four q-lanes of a row cover one contiguous 64 B segment, the table is offset-major so the
+//              16 indices of an offset are one 64 B read.
+//   * math   : v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain): the float4 just gathered feeds 4 MFMAs
+//              (k-slot q <-> channel 4q+t), A never touches LDS.  Offsets none of the 16 rows has are skipped.
+//   * weights: pre-permuted once per call into MFMA-fragment order Wf[k][ch][t][nb][lane] and kept in LDS
+//              (up to 150 KB of the 160 KB/CU), so a B fragment is one conflict-free ds_read_b32 row.
+//   * fusion : BatchNorm(+ReLU) of the INPUT is applied in the gather (a = max(0, x*scale+shift) on valid
+//              rows only); residual add in the epilogue; backward-data applies the ReLU mask of the fused
+//              BN and accumulates the two BN-backward channel sums in its epilogue.
+// Backward-weight is a second kernel: dW[k] = sum_i act(in[nbr[k][i]])^T dout[i] on the same MFMA, rows as
+// the reduction dimension, several offsets per wave sharing the dout fragment.
+#include "common.h"
+#include "../../include/minsu3d_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_NBT = 8;             // column blocks (of 16) a wave accumulates
+constexpr size_t LDS_BUDGET = 150 * 1024;
+
+struct ConvArgs {
+    const float *in;         // [Vin, Cin]
+    const float *wf;         // fragment-major weights
+    const int *nbr;          // [K][Vout]
+    float *out;              // [Vout, Cout]
+    const float *pre_scale;  // [Cin] or null : a = max(0, x*scale + shift)
+    const float *pre_shift;
+    const float *residual;   // [Vout, Cout] or null, added in the epilogue
+    // backward-data epilogue of a fused BN+ReLU (all null when unused)
+    const float *bn_x;       // [Vout, Cout] input of the fused BN (forward)
+    const float *bn_scale;   // [Cout]
+    const float *bn_shift;   // [Cout]
+    const float *bn_mean;    // [Cout]
+    const float *bn_invstd;  // [Cout]
+    float *bn_partial;       // [gridDim.x][2][Cout] : sum(dz), sum(dz * xhat)
+    int Vout, K, Cin, Cout;
+    int NCH;    // ceil(Cin / 16)
+    int NBtot;  // Cout / 16
+    int G;      // offsets whose weights are LDS resident at once
+    int ntiles;
+    int pre_relu;
+};
+
+// ------------------------------------------------------------------ weight permutation
+// Wf[((k*NCH + ch)*4 + t)*NBtot + nb][lane] = Weff[k][c = 16ch + 4q + t][j = 16nb + (lane & 15)],  q = lane >> 4
+__global__ void prep_weights_kernel(const float *__restrict__ W, float *__restrict__ wf, int K, int Cin_e, int Cout_e,
+                                    int NCH, int NBtot, int transpose, int mirror)
+{
+    const long total = (long)K * NCH * 4 * NBtot * 64;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(o & 63);
+        long r = o >> 6;
+        const int nb = (int)(r % NBtot); r /= NBtot;
+        const int t = (int)(r & 3); r >>= 2;
+        const int ch = (int)(r % NCH);
+        const int k = (int)(r / NCH);
+        const int c = 16 * ch + 4 * (lane >> 4) + t, j = 16 * nb + (lane & 15);
+        const int ks = mirror ? (K - 1 - k) : k;
+        float v = 0.f;
+        if (c < Cin_e && j < Cout_e)
+            v = transpose ? W[((size_t)ks * Cout_e + j) * Cin_e + c]   // original layout [K][Cout_e(=Cin_o)][Cin_e(=Cout_o)]
+                          : W[((size_t)ks * Cin_e + c) * Cout_e + j];
+        wf[o] = v;
+    }
+}
+
+// ------------------------------------------------------------------ forward / backward-data
+template <int NBT, bool ALIGNED>
+__device__ __forceinline__ void accumulate_offset(const ConvArgs &p, const float *__restrict__ sW, int kk, int idx,
+                                                  int q, int nb0, f32x4 (&acc)[NBT])
+{
+    const int l = lane_id();
+    for (int ch = 0; ch < p.NCH; ch++) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = 16 * ch + 4 * q;
+        if (idx >= 0) {
+            const float *row = p.in + (size_t)idx * p.Cin + c0;
+            if (ALIGNED) {
+                a = *reinterpret_cast<const f32x4 *>(row);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (c0 + t < p.Cin) a[t] = row[t];
+            }
+            if (p.pre_scale) {
+                f32x4 s, b;
+                if (ALIGNED) {
+                    s = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
+                    b = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        s[t] = (c0 + t < p.Cin) ? p.pre_scale[c0 + t] : 0.f;
+                        b[t] = (c0 + t < p.Cin) ? p.pre_shift[c0 + t] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float v = fmaf(a[t], s[t], b[t]);
+                    a[t] = p.pre_relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+        const float *w = sW + ((size_t)((kk * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
+        }
+    }
+}
+
+template <int NBT>
+__device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0, f32x4 (&acc)[NBT], float *s_part)
+{
+    const int l = lane_id(), q = l >> 4, jl = l & 15;
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++) {
+        const int j = 16 * (nb0 + nb) + jl;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = row0 + 4 * q + r;  // C/D layout: row = 4*(lane>>4) + reg, col = lane & 15
+            if (row < p.Vout) {
+                float v = acc[nb][r];
+                const size_t o = (size_t)row * p.Cout + j;
+                if (p.residual) v += p.residual[o];
+                if (p.bn_x) {
+                    // backward of the fused BN+ReLU that fed the forward conv: dz = da * [x*scale+shift > 0]
+                    const float x = p.bn_x[o];
+                    const float z = fmaf(x, p.bn_scale[j], p.bn_shift[j]);
+                    v = (z > 0.f) ? v : 0.f;
+                    s1 += v;
+                    s2 += v * ((x - p.bn_mean[j]) * p.bn_invstd[j]);
+                }
+                p.out[o] = v;
+            }
+        }
+        if (p.bn_x) {
+            // reduce over the 4 q-groups (same column), then one LDS atomic per column per wave
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (q == 0) {
+                atomicAdd(&s_part[j], s1);
+                atomicAdd(&s_part[p.Cout + j], s2);
+            }
+        }
+    }
+}
+
+template <int NBT, bool ALIGNED>
+__global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    const int l = lane_id(), q = l >> 4;
+    const int waves = blockDim.x >> 6;
+    const int nb0 = blockIdx.y * NBT;
+    float *sW = lds;
+    float *s_part = lds + (size_t)p.G * p.NCH * 4 * p.NBtot * 64;  // [2*Cout] when bn_x
+    const size_t per_offset = (size_t)p.NCH * 4 * p.NBtot * 64;
+
+    if (p.bn_x) {
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    }
+    // XCD-aware placement: blocks b, b+8, b+16.. share an XCD (dispatch is round-robin), give them adjacent tiles
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (nblk % 8 != 0) vb = blockIdx.x;  // only remap when it is a bijection
+
+    if (p.G >= p.K) {
+        // all weights resident: persistent waves walk a contiguous range of tiles
+        for (size_t t = threadIdx.x; t < per_offset * p.K / 4; t += blockDim.x)
+            reinterpret_cast<f32x4 *>(sW)[t] = reinterpret_cast<const f32x4 *>(p.wf)[t];
+        __syncthreads();
+        const int total_waves = nblk * waves;
+        const int chunk = (p.ntiles + total_waves - 1) / total_waves;
+        const int wglobal = vb * waves + wave_id();
+        const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
+        for (int tile = t_begin; tile < t_end; tile++) {
+            const int row0 = tile * 16;
+            const int my_row = row0 + (l & 15);
+            f32x4 acc[NBT];
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < p.K; k++) {
+                const int idx = (my_row < p.Vout) ? p.nbr[(size_t)k * p.Vout + my_row] : -1;
+                if (__ballot(idx >= 0) == 0ull) continue;
+                accumulate_offset<NBT, ALIGNED>(p, sW, k, idx, q, nb0, acc);
+            }
+            store_tile<NBT>(p, row0, nb0, acc, s_part);
+        }
+    } else {
+        // weights streamed through LDS in groups of G offsets; one tile per wave, accumulators stay in registers
+        const int tile = vb * waves + wave_id();
+        const int row0 = tile * 16;
+        const int my_row = row0 + (l & 15);
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < p.K; g0 += p.G) {
+            const int gn = min(p.G, p.K - g0);
+            __syncthreads();
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wf + per_offset * g0);
+            for (size_t t = threadIdx.x; t < per_offset * gn / 4; t += blockDim.x) reinterpret_cast<f32x4 *>(sW)[t] = src[t];
+            __syncthreads();
+            if (tile < p.ntiles) {
+                for (int kk = 0; kk < gn; kk++) {
+                    const int idx = (my_row < p.Vout) ? p.nbr[(size_t)(g0 + kk) * p.Vout + my_row] : -1;
+                    if (__ballot(idx >= 0) == 0ull) continue;
+                    accumulate_offset<NBT, ALIGNED>(p, sW, kk, idx, q, nb0, acc);
+                }
+            }
+        }
+        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
+    }
+    if (p.bn_x) {
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        // each blockIdx.y owns its own columns; others stay zero and are summed away by the finalize kernel
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT>
+int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
+{
+    if (aligned) {
+        if (lds > 64 * 1024)
+            MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_kernel<NBT, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        spconv_fwd_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
+    } else {
+        if (lds > 64 * 1024)
+            MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_kernel<NBT, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        spconv_fwd_kernel<NBT, false><<<grid, threads, lds, stream>>>(p);
+    }
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward-weight
+struct WgradArgs {
+    const float *in;         // [Vin, Cin]
+    const float *dout;       // [Vout, Cout]
+    const int *nbr;          // [K][Vout]
+    float *dW;               // [K, Cin, Cout], pre-zeroed, accumulated with float atomics
+    const float *pre_scale;  // fused BN(+ReLU) on `in` (recomputed), or null
+    const float *pre_shift;
+    int Vout, K, Cin, Cout, NBtot, rows_per_block, pre_relu;
+};
+
+// grid: x = row chunk, y = offset group (KG offsets), z = 16-channel input chunk
+template <int KG, int NBT>
+__global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
+{
+    __shared__ float s_red[4][64];  // cross-wave reduction scratch (one fragment at a time)
+    const int l = lane_id(), q = l >> 4, cl = l & 15;
+    const int k0 = blockIdx.y * KG;
+    const int c = blockIdx.z * 16 + cl;      // input channel owned by this lane's A element
+    const bool c_ok = c < p.Cin;
+    const float sc = (p.pre_scale && c_ok) ? p.pre_scale[c] : 1.f;
+    const float sh = (p.pre_scale && c_ok) ? p.pre_shift[c] : 0.f;
+    f32x4 acc[KG][NBT];
+#pragma unroll
+    for (int a = 0; a < KG; a++)
+#pragma unroll
+        for (int b = 0; b < NBT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int r_begin = blockIdx.x * p.rows_per_block;
+    const int r_end = min(p.Vout, r_begin + p.rows_per_block);
+    for (int r0 = r_begin + wave_id() * 4; r0 < r_end; r0 += 4 * (blockDim.x >> 6)) {
+        const int row = r0 + q;  // k-slot q of the MFMA <-> row r0 + q
+        const bool row_ok = row < r_end;
+        float b[NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+            b[nb] = (row_ok && 16 * nb + cl < p.Cout) ? p.dout[(size_t)row * p.Cout + 16 * nb + cl] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KG; kk++) {
+            const int k = k0 + kk;
+            int idx = -1;
+            if (k < p.K && row_ok) idx = p.nbr[(size_t)k * p.Vout + row];
+            if (__ballot(idx >= 0) == 0ull) continue;
+            float a = 0.f;
+            if (idx >= 0 && c_ok) {
+                a = p.in[(size_t)idx * p.Cin + c];
+                if (p.pre_scale) {
+                    a = fmaf(a, sc, sh);
+                    if (p.pre_relu) a = fmaxf(a, 0.f);
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nb], acc[kk][nb], 0, 0, 0);
+        }
+    }
+    // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int kk = 0; kk < KG; kk++) {
+        const int k = k0 + kk;
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // sum the waves of this block in LDS first: one global atomic per element per block
+                __syncthreads();
+                s_red[wave_id()][l] = acc[kk][nb][r];
+                __syncthreads();
+                if (wave_id() == 0) {
+                    float v = 0.f;
+                    for (int w = 0; w < nw; w++) v += s_red[w][l];
+                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
+                    if (k < p.K && ci < p.Cin && j < p.Cout && v != 0.f)
+                        atomicAdd(&p.dW[((size_t)k * p.Cin + ci) * p.Cout + j], v);
+                }
+            }
+        }
+    }
+}
+
+template <int KG, int NBT>
+int launch_wgrad(const WgradArgs &p, hipStream_t stream)
+{
+    const int nblk_rows = ms3d_divup(p.Vout, p.rows_per_block);
+    dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
+    spconv_wgrad_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ BN helper kernels
+// column sums over a [nparts][2][C] partial buffer -> mean / invstd / scale / shift (+ running stats)
+__global__ void bn_finalize_stats_kernel(const float *__restrict__ partial, int nparts, int C, long V, float eps,
+                                         float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                         float *running_mean, float *running_var, float *__restrict__ mean_out,
+                                         float *__restrict__ invstd_out, float *__restrict__ scale_out,
+                                         float *__restrict__ shift_out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; p++) {
+        s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
+        s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
+    }
+    const double mean = s1 / (double)V;
+    double var = s2 / (double)V - mean * mean;  // biased, as torch BatchNorm uses for normalisation
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = g * invstd;
+    shift_out[c] = b - (float)mean * g * invstd;
+    if (running_mean) {
+        const double unbiased = (V > 1) ? var * (double)V / (double)(V - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// per-block partial (sum, sum of squares) per channel; rows striped over blocks, lanes over channels
+__global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float *__restrict__ x, long V, int C,
+                                                               float *__restrict__ partial, int rows_per_block)
+{
+    extern __shared__ float s_acc[];  // [2][C]
+    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) s_acc[t] = 0.f;
+    __syncthreads();
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = min(V, r_begin + rows_per_block);
+    // thread t handles flat elements t, t+256, ... of the block's row range: fully coalesced
+    const long e_begin = r_begin * C, e_end = r_end * C;
+    const int step = blockDim.x;
+    {
+        // channel of element e is e % C; accumulate privately when the channel is loop invariant
+        if (step % C == 0) {
+            const int c = threadIdx.x % C;
+            float s1 = 0.f, s2 = 0.f;
+            for (long e = e_begin + threadIdx.x; e < e_end; e += step) {
+                const float v = x[e];
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+            atomicAdd(&s_acc[c], s1);
+            atomicAdd(&s_acc[C + c], s2);
+        } else {
+            for (long e = e_begin + threadIdx.x; e < e_end; e += step) {
+                const float v = x[e];
+                const int c = (int)(e % C);
+                atomicAdd(&s_acc[c], v);
+                atomicAdd(&s_acc[C + c], v * v);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];
+}
+
+// y = x*scale + shift (optionally ReLU): the stand-alone BN(+ReLU) at the end of the U-Net
+__global__ void bn_apply_kernel(const float *__restrict__ x, long n, int C, const float *__restrict__ scale,
+                                const float *__restrict__ shift, int relu, float *__restrict__ y)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        float v = fmaf(x[e], scale[c], shift[c]);
+        y[e] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// dx = scale * (dz - s1/V - xhat * s2/V)   (in place on dz allowed); s1 = sum dz, s2 = sum dz*xhat
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *__restrict__ x, long n, int C, long V,
+                                    const float *__restrict__ scale, const float *__restrict__ mean,
+                                    const float *__restrict__ invstd, const float *__restrict__ s1s2,
+                                    float *__restrict__ dx)
+{
+    const float invV = 1.f / (float)V;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const float xh = (x[e] - mean[c]) * invstd[c];
+        dx[e] = scale[c] * (dz[e] - s1s2[c] * invV - xh * s1s2[C + c] * invV);
+    }
+}
+
+// stand-alone BN(+ReLU) backward, stage 1: dz = dy * [relu mask]; partial sums of dz and dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             long V, int C, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, int relu,
+                                                             float *__restrict__ dz, float *__restrict__ partial,
+                                                             int rows_per_block)
+{
+    extern __shared__ float s_acc[];
+    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) s_acc[t] = 0.f;
+    __syncthreads();
+    const long e_begin = (long)blockIdx.x * rows_per_block * C;
+    const long e_end = min(V, (long)(blockIdx.x + 1) * rows_per_block) * C;
+    for (long e = e_begin + threadIdx.x; e < e_end; e += blockDim.x) {
+        const int c = (int)(e % C);
+        const float xv = x[e];
+        float g = dy[e];
+        if (relu && !(fmaf(xv, scale[c], shift[c]) > 0.f)) g = 0.f;
+        dz[e] = g;
+        atomicAdd(&s_acc[c], g);
+        atomicAdd(&s_acc[C + c], g * ((xv - mean[c]) * invstd[c]));
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];
+}
+
+__global__ void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; p++) s += (double)partial[(size_t)p * n + t];
+    out[t] = (float)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms3d_spconv_wf_floats(int K, int Cin, int Cout) { return (size_t)K * ms3d_divup(Cin, 16) * 4 * (Cout / 16) * 64; }
+
+int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, int transpose, int mirror, float *wf,
+                             ms3d_stream_t stream)
+{
+    if (Cout_eff % 16 != 0) return MS3D_E_UNSUPPORTED;
+    const int NCH = ms3d_divup(Cin_eff, 16), NBtot = Cout_eff / 16;
+    const long total = (long)K * NCH * 4 * NBtot * 64;
+    prep_weights_kernel<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
+        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
+{
+    // number of [2][Cout] partial rows a fused-BN backward-data launch writes (gridDim.x * gridDim.y)
+    const int NCH = ms3d_divup(Cin, 16), NBtot = Cout / 16;
+    const int ny = ms3d_divup(NBtot, MAX_NBT);
+    const size_t per_offset = (size_t)NCH * 4 * NBtot * 64 * sizeof(float);
+    const bool resident = per_offset * K + 2 * Cout * sizeof(float) <= LDS_BUDGET;
+    const int ntiles = ms3d_divup(Vout, 16);
+    int nblk;
+    if (resident) {
+        nblk = ms3d_divup(ntiles, 4);
+        if (nblk > 1024) nblk = 1024;
+    } else
+        nblk = ms3d_divup(ntiles, 16);
+    if (nblk < 1) nblk = 1;
+    return nblk * ny;
+}
+
+// out = conv(act(in)) [+ residual]; see ConvArgs.  wf from ms3d_spconv_prep_weights.
+int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
+                        float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
+                        const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
+                        const float *bn_mean, const float *bn_invstd, float *bn_partial, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Vout <= 0) return 0;
+    if (Cout % 16 != 0) return MS3D_E_UNSUPPORTED;
+    ConvArgs p;
+    p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+    p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
+    p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
+    p.NCH = ms3d_divup(Cin, 16); p.NBtot = Cout / 16; p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
+    const int ny = ms3d_divup(p.NBtot, MAX_NBT);
+    const int nbt = ms3d_divup(p.NBtot, ny);
+    if (p.NBtot % ny != 0) return MS3D_E_UNSUPPORTED;  // column blocks must split evenly (true for 16..224)
+    const size_t per_offset = (size_t)p.NCH * 4 * p.NBtot * 64 * sizeof(float);
+    const size_t extra = bn_x ? 2 * (size_t)Cout * sizeof(float) : 0;
+    const bool resident = per_offset * K + extra <= LDS_BUDGET;
+    int threads, nblk;
+    if (resident) {
+        p.G = K;
+        threads = 256;
+        nblk = ms3d_divup(p.ntiles, 4);
+        if (nblk > 1024) nblk = 1024;
+    } else {
+        p.G = (int)((LDS_BUDGET - extra) / per_offset);
+        if (p.G < 1) return MS3D_E_UNSUPPORTED;
+        threads = 1024;
+        nblk = ms3d_divup(p.ntiles, 16);
+    }
+    if (nblk < 1) nblk = 1;
+    const size_t lds = per_offset * p.G + extra;
+    dim3 grid(nblk, ny);
+    const bool aligned = (Cin % 16 == 0);
+    switch (nbt) {
+        case 1: return launch_fwd<1>(p, grid, threads, lds, aligned, stream);
+        case 2: return launch_fwd<2>(p, grid, threads, lds, aligned, stream);
+        case 3: return launch_fwd<3>(p, grid, threads, lds, aligned, stream);
+        case 4: return launch_fwd<4>(p, grid, threads, lds, aligned, stream);
+        case 5: return launch_fwd<5>(p, grid, threads, lds, aligned, stream);
+        case 6: return launch_fwd<6>(p, grid, threads, lds, aligned, stream);
+        case 7: return launch_fwd<7>(p, grid, threads, lds, aligned, stream);
+        case 8: return launch_fwd<8>(p, grid, threads, lds, aligned, stream);
+    }
+    return MS3D_E_UNSUPPORTED;
+}
+
+int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
+                                float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
+                                ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, stream));
+    if (Vout <= 0) return 0;
+    if (Cout % 16 != 0) return MS3D_E_UNSUPPORTED;
+    WgradArgs p;
+    p.in = in; p.dout = dout; p.nbr = nbr; p.dW = dW; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+    p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = Cout / 16; p.pre_relu = pre_relu;
+    // enough row chunks to fill the chip, but each long enough to amortise the final reduction
+    int chunks = ms3d_divup(Vout, 2048);
+    if (chunks > 512) chunks = 512;
+    p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
+    const int nb = p.NBtot;
+    if (nb > 14) return MS3D_E_UNSUPPORTED;
+    // KG * NBT <= 28 accumulators of 4 VGPRs
+    if (nb == 1) return (K >= 27) ? launch_wgrad<27, 1>(p, stream) : launch_wgrad<8, 1>(p, stream);
+    if (nb == 2) return (K >= 27) ? launch_wgrad<9, 2>(p, stream) : launch_wgrad<8, 2>(p, stream);
+    if (nb == 3) return (K >= 27) ? launch_wgrad<9, 3>(p, stream) : launch_wgrad<8, 3>(p, stream);
+    if (nb == 4) return launch_wgrad<4, 4>(p, stream);
+    if (nb == 5) return launch_wgrad<4, 5>(p, stream);
+    if (nb == 6) return launch_wgrad<4, 6>(p, stream);
+    if (nb == 7) return launch_wgrad<4, 7>(p, stream);
+    if (nb == 8) return launch_wgrad<3, 8>(p, stream);
+    if (nb <= 10) return launch_wgrad<2, 10>(p, stream);
+    if (nb <= 12) return launch_wgrad<2, 12>(p, stream);
+    return launch_wgrad<2, 14>(p, stream);
+}
+
+// training-mode batch statistics of x [V, C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale,
+// running stats updated in place (momentum, unbiased variance) like torch.nn.BatchNorm1d
+int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,
+                  float *running_mean, float *running_var, float *mean, float *invstd, float *scale, float *shift,
+                  float *partial_ws, int partial_rows, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V <= 0) return MS3D_E_UNSUPPORTED;
+    int nblk = (int)((V + 1023) / 1024);
+    if (nblk > partial_rows) nblk = partial_rows;
+    if (nblk < 1) nblk = 1;
+    const int rows_per_block = (int)((V + nblk - 1) / nblk);
+    bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
+    MS3D_LAUNCH_CHECK();
+    bn_finalize_stats_kernel<<<ms3d_divup(C, 64), 64, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
+                                                                  running_mean, running_var, mean, invstd, scale, shift);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float *shift, int relu, float *y,
+                  ms3d_stream_t stream)
+{
+    const long n = V * C;
+    if (n <= 0) return 0;
+    bn_apply_kernel<<<(int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), 256, 0, (hipStream_t)stream>>>(x, n, C, scale,
+                                                                                                             shift, relu, y);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// s1s2 [2][C] = column sums of a [nparts][2][C] partial buffer (fixed order -> deterministic)
+int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream)
+{
+    reduce_partial_kernel<<<ms3d_divup(n, 64), 64, 0, (hipStream_t)stream>>>(partial, nparts, n, out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
+                      const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream)
+{
+    const long n = V * C;
+    if (n <= 0) return 0;
+    bn_bwd_apply_kernel<<<(int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), 256, 0, (hipStream_t)stream>>>(
+        dz, x, n, C, V, scale, mean, invstd, s1s2, dx);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const float *scale, const float *shift,
+                        const float *mean, const float *invstd, int relu, float *dz, float *partial_ws,
+                        int partial_rows, int *nparts_out, ms3d_stream_t stream)
+{
+    int nblk = (int)((V + 1023) / 1024);
+    if (nblk > partial_rows) nblk = partial_rows;
+    if (nblk < 1) nblk = 1;
+    const int rows_per_block = (int)((V + nblk - 1) / nblk);
+    bn_bwd_partial_kernel<<<nblk, 256, 2 * C * sizeof(float), (hipStream_t)stream>>>(dy, x, V, C, scale, shift, mean,
+                                                                                    invstd, relu, dz, partial_ws,
+                                                                                    rows_per_block);
+    MS3D_LAUNCH_CHECK();
+    *nparts_out = nblk;
+    return 0;
+}
+
+}  // extern "C"

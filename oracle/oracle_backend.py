@@ -1,0 +1,143 @@
+"""CPU test double for minsu3d_amd.backend.HipBackend -- TEST INFRASTRUCTURE ONLY.
+
+Same method surface, CPU torch tensors in and out, every operator answered by the oracle
+(oracle/liboracle.so + a few lines of torch for the BatchNorm algebra).  Installed with
+`minsu3d_amd.backend.set_backend(OracleBackend())` by tests/, by bench.py's cpu_baseline leg and by the
+config-1 CPU plumbing run; the product package never imports it.
+"""
+import numpy as np
+import torch
+
+from . import oracle as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t if dtype is None else t.to(dtype)
+
+
+class OracleBackend:
+    name = "oracle-cpu"
+
+    # ---------------------------------------------------------------- grouping
+    def ballquery_batch_p(self, coords, batch_idxs, batch_offsets, radius, meanActive, max_scene_points=0):
+        idx, sl = O.ballquery_batch_p(_np(coords), _np(batch_idxs), _np(batch_offsets), radius)
+        return _t(idx), _t(sl)
+
+    def pg_bfs_cluster(self, sem, idx, start_len, threshold):
+        a, b = O.pg_bfs_cluster(_np(sem), _np(idx), _np(start_len), threshold)
+        return _t(a.reshape(-1, 2)), _t(b)
+
+    def sg_bfs_cluster(self, mean, idx, start_len, threshold, class_id):
+        a, b = O.sg_bfs_cluster(np.asarray(mean, np.float32), _np(idx), _np(start_len), threshold, class_id)
+        return _t(a.reshape(-1, 2)), _t(b)
+
+    def hierarchical_aggregation(self, sem, coord_shift, idx, start_len, batch_idxs, using_set_aggr, pna, ra,
+                                 ignored_label):
+        a, b = O.hierarchical_aggregation(_np(sem), _np(coord_shift), _np(idx), _np(start_len), _np(batch_idxs),
+                                          using_set_aggr, np.asarray(pna, np.float32), np.asarray(ra, np.float32),
+                                          ignored_label)
+        return _t(a.reshape(-1, 2)), _t(b)
+
+    def sec_mean(self, x, off): return _t(O.sec_mean(_np(x), _np(off)))
+    def sec_min(self, x, off): return _t(O.sec_min(_np(x), _np(off)))
+    def sec_max(self, x, off): return _t(O.sec_max(_np(x), _np(off)))
+    def global_avg_pool_fp(self, x, off): return _t(O.global_avg_pool_fp(_np(x), _np(off)))
+
+    def roipool_fp(self, x, off):
+        a, b = O.roipool_fp(_np(x), _np(off))
+        return _t(a), _t(b)
+
+    def roipool_bp(self, d_out, off, maxidx, n): return _t(O.roipool_bp(_np(d_out), _np(off), _np(maxidx), n))
+    def global_avg_pool_bp(self, d_out, off, n): return _t(O.global_avg_pool_bp(_np(d_out), _np(off), n))
+    def get_iou(self, pi, po, il, pn): return _t(O.get_iou(_np(pi), _np(po), _np(il), _np(pn)))
+    def get_mask_iou_on_cluster(self, pi, po, il, pn): return _t(O.get_mask_iou_on_cluster(_np(pi), _np(po), _np(il), _np(pn)))
+    def get_mask_iou_on_pred(self, pi, po, il, pn, sg): return _t(O.get_mask_iou_on_pred(_np(pi), _np(po), _np(il), _np(pn), _np(sg)))
+
+    def get_mask_label(self, pi, po, il, ic, iou, ignored_label, iou_thr):
+        a, b = O.get_mask_label(_np(pi), _np(po), _np(il), _np(ic), _np(iou), ignored_label, iou_thr)
+        return _t(a), _t(b)
+
+    # ---------------------------------------------------------------- coordinates (tables offset-major [K, V])
+    def sparse_quantize(self, coords):
+        u, inv = O.sparse_quantize(_np(coords))
+        return _t(u), _t(inv)
+
+    def kmap_k3(self, coords, ts):
+        return _t(O.kmap_k3(_np(coords), ts).T)
+
+    def downsample(self, coords, ts):
+        oc, par, ko = O.downsample(_np(coords), ts)
+        return _t(oc), _t(par), _t(ko)
+
+    def kmap_k2(self, parent, koff, vc):
+        d, u = O.kmap_k2(_np(parent), _np(koff), int(vc))
+        return _t(d.T), _t(u.T)
+
+    # ---------------------------------------------------------------- convolution
+    def prep_weights(self, W, K, cin_e, cout_e, transpose=False, mirror=False):
+        W = _np(W).reshape(K, -1, cout_e if not transpose else cin_e)
+        if transpose:
+            W = np.ascontiguousarray(W.transpose(0, 2, 1))   # [K, cin_e(=cout_o), cout_e(=cin_o)]
+        if mirror:
+            W = np.ascontiguousarray(W[::-1])
+        return np.ascontiguousarray(W, np.float32)
+
+    @staticmethod
+    def _act(x, pre, pre_relu):
+        if pre is None:
+            return x
+        a = x * pre[0] + pre[1]
+        return torch.relu(a) if pre_relu else a
+
+    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None):
+        a = self._act(x.detach(), pre, pre_relu)
+        out = _t(O.conv_fwd(_np(a), wf, _np(nbr).T))
+        if residual is not None:
+            out = out + residual
+        if bn_bwd is None:
+            return out
+        bx, scale, shift, mean, invstd = bn_bwd
+        dz = out * ((bx * scale + shift) > 0)
+        xh = (bx - mean) * invstd
+        return dz, torch.stack([dz.sum(0), (dz * xh).sum(0)])
+
+    def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):
+        a = self._act(x.detach(), pre, pre_relu)
+        return _t(O.conv_bwd_weight(_np(a), _np(dout), _np(nbr).T, K))
+
+    # ---------------------------------------------------------------- batch norm algebra
+    def bn_stats(self, x, eps, momentum, gamma, beta, running_mean, running_var):
+        V = x.size(0)
+        xd = x.double()
+        mean = xd.mean(0)
+        var = (xd * xd).mean(0) - mean * mean
+        var = var.clamp_min(0)
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        g = gamma if gamma is not None else torch.ones_like(invstd)
+        b = beta if beta is not None else torch.zeros_like(invstd)
+        scale = g * invstd
+        shift = b - mean.float() * scale
+        if running_mean is not None:
+            unbiased = var * V / max(V - 1, 1)
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * unbiased.float())
+        return mean.float(), invstd, scale, shift
+
+    def bn_apply(self, x, scale, shift, relu):
+        y = x * scale + shift
+        return torch.relu(y) if relu else y
+
+    def bn_bwd_reduce(self, dy, x, scale, shift, mean, invstd, relu):
+        dz = dy * ((x * scale + shift) > 0) if relu else dy.clone()
+        xh = (x - mean) * invstd
+        return dz, torch.stack([dz.sum(0), (dz * xh).sum(0)])
+
+    def bn_bwd_apply(self, dz, x, scale, mean, invstd, s1s2):
+        V = x.size(0)
+        xh = (x - mean) * invstd
+        return scale * (dz - s1s2[0] / V - xh * s1s2[1] / V)

@@ -1,0 +1,174 @@
+"""GPU parity of the sparse-voxel engine (through the C ABI): coordinate maps bit-exact vs the oracle, conv /
+BN kernels within 1e-4 relative of the oracle and of a plain torch fp32 restatement."""
+import numpy as np
+import pytest
+import torch
+
+from sparse_ref import random_sparse, ref_conv
+from test_sparse_cpu import _unet_like, run_me_chain, run_ref_chain
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4   # north_star: sparse-conv activations within 1e-4 relative
+
+
+@pytest.fixture(scope="module")
+def be():
+    from minsu3d_amd.backend import HipBackend
+    return HipBackend()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def surface_coords(rng, B, n, extent=60):
+    """ScanNet-like: points on a few planes -> sparse 3-D neighbourhoods (avg ~7-12 of 27)"""
+    pts = []
+    for b in range(B):
+        m = n // B
+        u, v = rng.integers(0, extent, m), rng.integers(0, extent, m)
+        which = rng.integers(0, 3, m)
+        w = rng.integers(0, 2, m) + extent // 3
+        xyz = np.stack([np.where(which == 0, w, u), np.where(which == 1, w, v), np.where(which == 2, w, np.where(which == 0, v, u))], 1)
+        pts.append(np.concatenate([np.full((m, 1), b), xyz], 1))
+    c = np.unique(np.concatenate(pts, 0).astype(np.int32), axis=0)
+    rng.shuffle(c)
+    return c
+
+
+def test_coordinate_maps_bit_exact(be, oracle):
+    rng = np.random.default_rng(0)
+    for ts in (1, 2, 4):
+        c = surface_coords(rng, 3, 30000)
+        c[:, 1:] *= ts
+        cd = dev(c)
+        assert np.array_equal(be.kmap_k3(cd, ts).cpu().numpy(), oracle.kmap_k3(c, ts).T)
+        oc, par, ko = be.downsample(cd, ts)
+        woc, wpar, wko = oracle.downsample(c, ts)
+        assert np.array_equal(oc.cpu().numpy(), woc) and np.array_equal(par.cpu().numpy(), wpar)
+        assert np.array_equal(ko.cpu().numpy(), wko)
+        d, u = be.kmap_k2(par, ko, oc.size(0))
+        wd, wu = oracle.kmap_k2(wpar, wko, woc.shape[0])
+        assert np.array_equal(d.cpu().numpy(), wd.T) and np.array_equal(u.cpu().numpy(), wu.T)
+    # quantize with duplicates: first occurrence wins
+    dup = np.concatenate([c, c[::3], c[5::7]], 0)
+    rng.shuffle(dup)
+    u, inv = be.sparse_quantize(dev(dup))
+    wu, winv = oracle.sparse_quantize(dup)
+    assert np.array_equal(u.cpu().numpy(), wu) and np.array_equal(inv.cpu().numpy(), winv)
+
+
+@pytest.mark.parametrize("cin,cout,K", [(16, 16, 27), (6, 16, 27), (32, 16, 27), (16, 32, 8), (32, 32, 27),
+                                        (48, 48, 27), (64, 32, 27), (112, 112, 27), (96, 112, 8), (32, 16, 1),
+                                        (224, 112, 27), (160, 160, 8)])
+def test_conv_kernels_vs_oracle(be, oracle, cin, cout, K):
+    rng = np.random.default_rng(cin * 1000 + cout + K)
+    big = cin * cout <= 32 * 32
+    c = surface_coords(rng, 2, 24000 if big else 3000)
+    V = c.shape[0]
+    if K == 27:
+        nbr = oracle.kmap_k3(c, 1)
+        nbr_bwd, vin, vout, mirror = nbr, V, V, True
+    elif K == 8:
+        oc, par, ko = oracle.downsample(c, 1)
+        nbr, nbr_bwd = oracle.kmap_k2(par, ko, oc.shape[0])
+        vin, vout, mirror = V, oc.shape[0], False
+    else:
+        nbr = np.arange(V, dtype=np.int32).reshape(V, 1)
+        nbr_bwd, vin, vout, mirror = nbr, V, V, False
+    x = rng.standard_normal((vin, cin)).astype(np.float32)
+    W = (rng.standard_normal((K, cin, cout)) / np.sqrt(cin * K)).astype(np.float32)
+    nbr_d = dev(nbr.T.copy()); nbr_bwd_d = dev(nbr_bwd.T.copy())
+    xd, Wd = dev(x), dev(W)
+    # forward
+    want = oracle.conv_fwd(x, W, nbr)
+    got = be.conv_forward(xd, be.prep_weights(Wd, K, cin, cout), nbr_d, vout, K, cin, cout)
+    assert rel_err(got.cpu(), torch.from_numpy(want)) < RTOL
+    # forward with the fused BN+ReLU prologue and residual epilogue
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32); shift = rng.uniform(-0.5, 0.5, cin).astype(np.float32)
+    res = rng.standard_normal((vout, cout)).astype(np.float32)
+    want2 = oracle.conv_fwd(np.maximum(x * scale + shift, 0), W, nbr) + res
+    got2 = be.conv_forward(xd, be.prep_weights(Wd, K, cin, cout), nbr_d, vout, K, cin, cout,
+                           pre=(dev(scale), dev(shift)), pre_relu=True, residual=dev(res))
+    assert rel_err(got2.cpu(), torch.from_numpy(want2)) < RTOL
+    # backward-data
+    g = rng.standard_normal((vout, cout)).astype(np.float32)
+    want_dx = oracle.conv_bwd_data(g, W, nbr, vin)
+    wft = be.prep_weights(Wd, K, cout, cin, transpose=True, mirror=mirror)
+    got_dx = be.conv_forward(dev(g), wft, nbr_bwd_d, vin, K, cout, cin)
+    assert rel_err(got_dx.cpu(), torch.from_numpy(want_dx)) < RTOL
+    # backward-data with the fused-BN epilogue
+    mean = x.mean(0); invstd = 1 / np.sqrt(x.var(0) + 1e-5)
+    dz, s1s2 = be.conv_forward(dev(g), wft, nbr_bwd_d, vin, K, cout, cin,
+                               bn_bwd=(xd, dev(scale), dev(shift), dev(mean.astype(np.float32)),
+                                       dev(invstd.astype(np.float32))))
+    mask = (x * scale + shift) > 0
+    want_dz = want_dx * mask
+    assert rel_err(dz.cpu(), torch.from_numpy(want_dz)) < RTOL
+    xh = (x - mean) * invstd
+    want_s = np.stack([want_dz.astype(np.float64).sum(0), (want_dz.astype(np.float64) * xh).sum(0)])
+    assert np.allclose(s1s2.cpu().numpy(), want_s, rtol=1e-3, atol=1e-3 * np.abs(want_s).max())
+    # backward-weight (plain and with the recomputed prologue)
+    want_dw = oracle.conv_bwd_weight(x, g, nbr, K)
+    got_dw = be.conv_backward_weight(xd, dev(g), nbr_d, vout, K, cin, cout)
+    assert rel_err(got_dw.cpu(), torch.from_numpy(want_dw)) < RTOL
+    want_dw2 = oracle.conv_bwd_weight(np.maximum(x * scale + shift, 0), g, nbr, K)
+    got_dw2 = be.conv_backward_weight(xd, dev(g), nbr_d, vout, K, cin, cout, pre=(dev(scale), dev(shift)), pre_relu=True)
+    assert rel_err(got_dw2.cpu(), torch.from_numpy(want_dw2)) < RTOL
+
+
+@pytest.mark.parametrize("C_", [16, 48, 112])
+def test_bn_kernels_vs_torch(be, C_):
+    torch.manual_seed(C_)
+    V = 50000
+    x = torch.randn(V, C_, device="cuda") * 2 + 0.7
+    gamma = torch.rand(C_, device="cuda") + 0.5; beta = torch.randn(C_, device="cuda")
+    rm = torch.zeros(C_, device="cuda"); rv = torch.ones(C_, device="cuda")
+    mean, invstd, scale, shift = be.bn_stats(x, 1e-5, 0.1, gamma, beta, rm, rv)
+    bn = torch.nn.BatchNorm1d(C_).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(bn(xr))
+    y = be.bn_apply(x, scale, shift, True)
+    assert rel_err(y, yr.detach()) < RTOL
+    assert torch.allclose(rm, bn.running_mean, atol=1e-5) and torch.allclose(rv, bn.running_var, rtol=1e-4)
+    g = torch.randn_like(y)
+    yr.backward(g)
+    dz, s1s2 = be.bn_bwd_reduce(g, x, scale, shift, mean, invstd, True)
+    dx = be.bn_bwd_apply(dz, x, scale, mean, invstd, s1s2)
+    assert rel_err(dx, xr.grad) < 5e-4
+    assert rel_err(s1s2[0], bn.bias.grad) < 5e-4 and rel_err(s1s2[1], bn.weight.grad) < 5e-4
+
+
+def test_mini_unet_hip_vs_torch(be):
+    """the ME module chain on the HIP backend (fused kernels, custom backward) vs plain torch ops on the GPU"""
+    import minsu3d_amd.MinkowskiEngine as ME
+    from minsu3d_amd import backend
+    prev = backend.set_backend(be)
+    try:
+        rng = np.random.default_rng(5)
+        c = surface_coords(rng, 2, 20000, extent=40)
+        feats = rng.standard_normal((c.shape[0], 6)).astype(np.float32)
+        net = _unet_like(ME).cuda()
+        ft = dev(feats).requires_grad_(True)
+        out = run_me_chain(ME, net, ft, dev(c))
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        got = {n: p.grad.clone() for n, p in net.named_parameters()}
+        gx = ft.grad.clone()
+        net.zero_grad(); ft.grad = None
+        cm = ME.CoordinateManager(dev(c))
+        ref = run_ref_chain(net, ft, cm)
+        assert rel_err(out, ref) < 5e-4
+        ref.backward(gout)
+        assert rel_err(gx, ft.grad) < 2e-3
+        for n, p in net.named_parameters():
+            assert rel_err(got[n], p.grad) < 2e-3, n
+    finally:
+        backend.set_backend(prev)
