@@ -131,11 +131,12 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
 #pragma unroll
     for (int nb = 0; nb < NBT; nb++) {
         const int j = 16 * (nb0 + nb) + jl;
+        const bool j_ok = j < p.Cout;  // Cout need not be a multiple of 16 (padded column block)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = row0 + 4 * q + r;  // C/D layout: row = 4*(lane>>4) + reg, col = lane & 15
-            if (row < p.Vout) {
+            if (row < p.Vout && j_ok) {
                 float v = acc[nb][r];
                 const size_t o = (size_t)row * p.Cout + j;
                 if (p.residual) v += p.residual[o];
@@ -154,7 +155,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
             // reduce over the 4 q-groups (same column), then one LDS atomic per column per wave
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (q == 0) {
+            if (q == 0 && j_ok) {
                 atomicAdd(&s_part[j], s1);
                 atomicAdd(&s_part[p.Cout + j], s2);
             }
@@ -477,13 +478,15 @@ __global__ void reduce_partial_kernel(const float *__restrict__ partial, int npa
 
 extern "C" {
 
-size_t ms3d_spconv_wf_floats(int K, int Cin, int Cout) { return (size_t)K * ms3d_divup(Cin, 16) * 4 * (Cout / 16) * 64; }
+size_t ms3d_spconv_wf_floats(int K, int Cin, int Cout)
+{
+    return (size_t)K * ms3d_divup(Cin, 16) * 4 * ms3d_divup(Cout, 16) * 64;
+}
 
 int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, int transpose, int mirror, float *wf,
                              ms3d_stream_t stream)
 {
-    if (Cout_eff % 16 != 0) return MS3D_E_UNSUPPORTED;
-    const int NCH = ms3d_divup(Cin_eff, 16), NBtot = Cout_eff / 16;
+    const int NCH = ms3d_divup(Cin_eff, 16), NBtot = ms3d_divup(Cout_eff, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64;
     prep_weights_kernel<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
         W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror);
@@ -494,7 +497,7 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
 {
     // number of [2][Cout] partial rows a fused-BN backward-data launch writes (gridDim.x * gridDim.y)
-    const int NCH = ms3d_divup(Cin, 16), NBtot = Cout / 16;
+    const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int ny = ms3d_divup(NBtot, MAX_NBT);
     const size_t per_offset = (size_t)NCH * 4 * NBtot * 64 * sizeof(float);
     const bool resident = per_offset * K + 2 * Cout * sizeof(float) <= LDS_BUDGET;
@@ -517,12 +520,11 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
-    if (Cout % 16 != 0) return MS3D_E_UNSUPPORTED;
     ConvArgs p;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
-    p.NCH = ms3d_divup(Cin, 16); p.NBtot = Cout / 16; p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
+    p.NCH = ms3d_divup(Cin, 16); p.NBtot = ms3d_divup(Cout, 16); p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
     const int ny = ms3d_divup(p.NBtot, MAX_NBT);
     const int nbt = ms3d_divup(p.NBtot, ny);
     if (p.NBtot % ny != 0) return MS3D_E_UNSUPPORTED;  // column blocks must split evenly (true for 16..224)
@@ -565,10 +567,9 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     hipStream_t stream = (hipStream_t)stream_;
     MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, stream));
     if (Vout <= 0) return 0;
-    if (Cout % 16 != 0) return MS3D_E_UNSUPPORTED;
     WgradArgs p;
     p.in = in; p.dout = dout; p.nbr = nbr; p.dW = dW; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
-    p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = Cout / 16; p.pre_relu = pre_relu;
+    p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = ms3d_divup(Cout, 16); p.pre_relu = pre_relu;
     // enough row chunks to fill the chip, but each long enough to amortise the final reduction
     int chunks = ms3d_divup(Vout, 2048);
     if (chunks > 512) chunks = 512;

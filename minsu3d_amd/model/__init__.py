@@ -1,0 +1,2 @@
+from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores  # noqa: F401
+from .pointgroup import PointGroup  # noqa: F401

@@ -1,0 +1,98 @@
+"""Base task module (reference minsu3d/model/general_model.py:16-213), LightningModule-shaped without
+Lightning: `hparams.cfg`, `current_epoch`, forward / _loss / training_step / configure_optimizers /
+on_train_epoch_end.  Also the proposal voxelisation and the score-target helper."""
+import importlib
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .. import MinkowskiEngine as ME
+from ..common_ops.functions import common_ops
+from ..loss import PTOffsetLoss
+from .module import Backbone
+
+
+class GeneralModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.hparams = SimpleNamespace(cfg=cfg)
+        self.current_epoch = 0
+        net = cfg.model.network
+        in_ch = 3 + 3 * int(net.use_color) + 3 * int(net.use_normal)
+        self.backbone = Backbone(input_channel=in_ch, output_channel=net.m, block_channels=net.blocks,
+                                 block_reps=net.block_reps, sem_classes=cfg.data.classes)
+        self.offset_criterion = PTOffsetLoss()
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def configure_optimizers(self):
+        opt = dict(self.hparams.cfg.model.optimizer)
+        mod, _, name = opt.pop("_target_").rpartition(".")
+        return getattr(importlib.import_module(mod), name)(params=self.parameters(), **opt)
+
+    def forward(self, data_dict):
+        return self.backbone(data_dict["voxel_features"], data_dict["voxel_xyz"], data_dict["voxel_point_map"])
+
+    def _loss(self, data_dict, output_dict):
+        sem = nn.functional.cross_entropy(output_dict["semantic_scores"], data_dict["sem_labels"].long(),
+                                          ignore_index=-1)
+        gt_offsets = data_dict["instance_center_xyz"] - data_dict["point_xyz"]
+        norm_l, dir_l = self.offset_criterion(output_dict["point_offsets"], gt_offsets,
+                                              valid_mask=data_dict["instance_ids"] != -1)
+        return {"semantic_loss": sem, "offset_norm_loss": norm_l, "offset_dir_loss": dir_l}
+
+    def training_step(self, data_dict, idx=0):
+        losses = self._loss(data_dict, self(data_dict))
+        total = sum(losses.values())
+        self.last_losses = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in losses.items()} \
+            if getattr(self, "log_losses", False) else None
+        return total
+
+    def on_train_epoch_end(self, optimizer):
+        """cosine decay from decay_start_epoch (reference util/lr_decay.py:7-12)"""
+        cfg = self.hparams.cfg.model
+        start, total, base, clip = cfg.lr_decay.decay_start_epoch, cfg.trainer.max_epochs, cfg.optimizer.lr, 1e-6
+        if self.current_epoch < start:
+            return
+        lr = clip + 0.5 * (base - clip) * (1 + math.cos(math.pi * (self.current_epoch - start) / (total - start)))
+        for g in optimizer.param_groups:
+            g["lr"] = lr
+
+
+def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None):
+    """Per-proposal recentre / rescale into a `spatial_shape` cube, random placement, integer cast, dedupe into
+    voxels (reference general_model.py:152-193).  `rand` = the two U(0,1)^3 draws shared by all proposals
+    (injected by parity tests).  -> (SparseTensor over proposal voxels, point->voxel map)"""
+    cluster_of = clusters_idx[:, 0].long()
+    point_of = clusters_idx[:, 1].long()
+    feats = feats[point_of]
+    xyz = coords[point_of]
+    xyz = xyz - common_ops.sec_mean(xyz.contiguous(), clusters_offset)[cluster_of]
+    lo = common_ops.sec_min(xyz.contiguous(), clusters_offset)
+    hi = common_ops.sec_max(xyz.contiguous(), clusters_offset)
+    # 0.01 keeps the scaled coordinates strictly inside the cube
+    c_scale = torch.clamp(1 / ((hi - lo) / spatial_shape).max(1)[0] - 0.01, min=None, max=scale)
+    lo, hi = lo * c_scale[:, None], hi * c_scale[:, None]
+    xyz = xyz * c_scale[cluster_of][:, None]
+    extent = hi - lo
+    u1, u2 = rand if rand is not None else (torch.rand(3, device=device), torch.rand(3, device=device))
+    shift = -lo + torch.clamp(spatial_shape - extent - 0.001, min=0) * u1
+    shift = shift + torch.clamp(spatial_shape - extent + 0.001, max=0) * u2
+    vox = (xyz + shift[cluster_of]).int()
+    batched = torch.cat((clusters_idx[:, 0].int().unsqueeze(-1), vox), dim=1).contiguous()
+    voxel_xyz, voxel_feats, _, p2v = ME.utils.sparse_quantize(batched, feats, return_index=True, return_inverse=True,
+                                                              device=device.type)
+    return ME.SparseTensor(features=voxel_feats, coordinates=voxel_xyz, device=device), p2v
+
+
+def get_segmented_scores(scores, fg_thresh=1.0, bg_thresh=0.0):
+    """1 above fg_thresh, 0 below bg_thresh, linear in between (reference general_model.py:196-213)"""
+    k = 1.0 / (fg_thresh - bg_thresh)
+    lin = scores * k + bg_thresh / (bg_thresh - fg_thresh)
+    out = (scores > fg_thresh).float()
+    mid = ~(scores > fg_thresh) & ~(scores < bg_thresh)
+    return torch.where(mid, lin, out)

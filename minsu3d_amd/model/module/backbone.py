@@ -1,0 +1,29 @@
+"""Sparse U-Net backbone + the two per-point heads (reference minsu3d/model/module/backbone.py:8-43)."""
+import torch.nn as nn
+
+from ... import MinkowskiEngine as ME
+from .common import ResidualBlock, UBlock
+
+
+def _head(c_in, c_out):
+    return nn.Sequential(nn.Linear(c_in, c_in), nn.BatchNorm1d(c_in), nn.ReLU(inplace=True), nn.Linear(c_in, c_out))
+
+
+class Backbone(nn.Module):
+    def __init__(self, input_channel, output_channel, block_channels, block_reps, sem_classes):
+        super().__init__()
+        m = output_channel
+        self.unet = nn.Sequential(
+            ME.MinkowskiConvolution(in_channels=input_channel, out_channels=m, kernel_size=3, dimension=3),
+            UBlock([m * c for c in block_channels], ME.MinkowskiBatchNorm, block_reps, ResidualBlock),
+            ME.MinkowskiBatchNorm(m),
+            ME.MinkowskiReLU(inplace=True))
+        self.semantic_branch = _head(m, sem_classes)
+        self.offset_branch = _head(m, 3)
+
+    def forward(self, voxel_features, voxel_coordinates, v2p_map):
+        x = ME.SparseTensor(features=voxel_features, coordinates=voxel_coordinates)
+        point_features = self.unet(x).features[v2p_map]          # voxel -> point broadcast
+        return {"point_features": point_features,
+                "semantic_scores": self.semantic_branch(point_features),
+                "point_offsets": self.offset_branch(point_features)}

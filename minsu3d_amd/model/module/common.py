@@ -1,0 +1,61 @@
+"""U-Net building blocks over the sparse engine.  Topology and sub-module names follow the reference
+(minsu3d/model/module/common.py:21-95) so state_dict keys are identical:
+  ResidualBlock : conv_branch = [BN, ReLU, conv3, BN, ReLU, conv3]  (+ `downsample` = [1x1 conv] when widths differ)
+  UBlock        : blocks -> (conv: [BN, ReLU, k2s2]) -> u -> (deconv: [BN, ReLU, k2s2^T]) -> cat -> blocks_tail
+Every [BN, ReLU, conv] triple executes as ONE fused gather kernel (lazy BN/ReLU, see MinkowskiEngine/tensor.py)."""
+from collections import OrderedDict
+
+import torch.nn as nn
+
+from ... import MinkowskiEngine as ME
+
+
+def _bn_relu_conv(norm_fn, c_in, conv):
+    return nn.Sequential(norm_fn(c_in), ME.MinkowskiReLU(inplace=True), conv)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, dimension=3, norm_fn=None):
+        super().__init__()
+        norm_fn = norm_fn or ME.MinkowskiBatchNorm
+        self.downsample = None
+        if in_channels != out_channels:   # 1x1 projection of the skip path
+            self.downsample = nn.Sequential(
+                ME.MinkowskiConvolution(in_channels, out_channels, kernel_size=1, dimension=dimension))
+        first = _bn_relu_conv(norm_fn, in_channels,
+                              ME.MinkowskiConvolution(in_channels, out_channels, kernel_size=3, dimension=dimension))
+        second = _bn_relu_conv(norm_fn, out_channels,
+                               ME.MinkowskiConvolution(out_channels, out_channels, kernel_size=3, dimension=dimension))
+        self.conv_branch = nn.Sequential(*first, *second)
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.conv_branch(x)
+        y += skip
+        return y
+
+
+class UBlock(nn.Module):
+    """recursive encoder/decoder level; n_planes = channel widths from this level down"""
+
+    def __init__(self, n_planes, norm_fn, block_reps, block):
+        super().__init__()
+        self.nPlanes = list(n_planes)
+        c = self.nPlanes[0]
+        self.blocks = nn.Sequential(OrderedDict(
+            (f"block{i}", block(c, c, 3, norm_fn)) for i in range(block_reps)))
+        if len(self.nPlanes) > 1:
+            c_next = self.nPlanes[1]
+            self.conv = _bn_relu_conv(norm_fn, c, ME.MinkowskiConvolution(c, c_next, kernel_size=2, stride=2, dimension=3))
+            self.u = UBlock(self.nPlanes[1:], norm_fn, block_reps, block)
+            self.deconv = _bn_relu_conv(
+                norm_fn, c_next, ME.MinkowskiConvolutionTranspose(c_next, c, kernel_size=2, stride=2, dimension=3))
+            self.blocks_tail = nn.Sequential(OrderedDict(
+                (f"block{i}", block(c * (2 - i), c, 3, norm_fn)) for i in range(block_reps)))
+
+    def forward(self, x):
+        skip = self.blocks(x)
+        if len(self.nPlanes) == 1:
+            return skip
+        up = self.deconv(self.u(self.conv(skip)))
+        return self.blocks_tail(ME.cat(skip, up))

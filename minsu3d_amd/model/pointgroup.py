@@ -1,0 +1,85 @@
+"""PointGroup (reference minsu3d/model/pointgroup.py:12-110): dual-set point grouping (original and
+offset-shifted coordinates) -> proposal voxelisation -> ScoreNet -> RoI max-pool -> score.
+Everything from the ball query to the clusters stays on the device (the reference round-trips through
+host memory for its serial BFS, pointgroup.py:41-66)."""
+import torch
+import torch.nn as nn
+
+from ..common_ops.functions import common_ops, pointgroup_ops
+from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores
+from .module import TinyUnet
+
+
+class PointGroup(GeneralModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        m = cfg.model.network.m
+        self.score_net = TinyUnet(m)
+        self.score_branch = nn.Linear(m, 1)
+        self.voxelization_rand = None   # tests inject the two uniform draws here
+
+    def _group(self, xyz, batch_idxs, batch_offsets, sem_fg, object_idxs, mean_active):
+        net = self.hparams.cfg.model.network.cluster
+        idx, start_len = common_ops.ballquery_batch_p(xyz, batch_idxs, batch_offsets, net.cluster_radius, mean_active)
+        prop_idx, prop_off = pointgroup_ops.pg_bfs_cluster(sem_fg, idx, start_len, net.cluster_npoint_thre)
+        prop_idx = prop_idx.long()
+        prop_idx[:, 1] = object_idxs[prop_idx[:, 1]]          # foreground index -> global point index
+        return prop_idx, prop_off
+
+    def forward(self, data_dict):
+        out = super().forward(data_dict)
+        cfg = self.hparams.cfg
+        net = cfg.model.network
+        if self.current_epoch <= net.prepare_epochs:
+            return out
+        # Synthetic benchmarks run a randomly initialised network, whose predictions group into nothing; they
+        # may supply the grouping INPUTS a trained network would produce (labels / offsets near the ground
+        # truth).  Every operator still runs, and the losses still use the network's own outputs.
+        sem_pred = data_dict.get("grouping_semantic_preds")
+        if sem_pred is None:
+            sem_pred = out["semantic_scores"].argmax(1).to(torch.int16)
+        grouping_offsets = data_dict.get("grouping_point_offsets")
+        if grouping_offsets is None:
+            grouping_offsets = out["point_offsets"]
+        fg = torch.ones_like(sem_pred, dtype=torch.bool)
+        for cls in cfg.data.ignore_classes:                    # floor / wall never form instances
+            fg &= sem_pred != (cls - 1)
+        object_idxs = torch.nonzero(fg).view(-1)
+        batch_idxs = data_dict["vert_batch_ids"][object_idxs]
+        batch_offsets = torch.cumsum(torch.bincount(batch_idxs + 1), dim=0).int()
+        xyz = data_dict["point_xyz"][object_idxs]
+        shifted = (xyz + grouping_offsets[object_idxs]).detach().contiguous()
+        sem_fg = sem_pred[object_idxs].contiguous()
+
+        p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
+                                       net.cluster.cluster_shift_meanActive)
+        p_orig, o_orig = self._group(xyz.contiguous(), batch_idxs, batch_offsets, sem_fg, object_idxs,
+                                     net.cluster.cluster_meanActive)
+        p_shift[:, 0] += o_orig.size(0) - 1                    # renumber the second proposal set after the first
+        proposals_idx = torch.cat((p_orig, p_shift), dim=0)
+        proposals_offset = torch.cat((o_orig, o_shift[1:] + o_orig[-1]))
+
+        if proposals_offset.numel() <= 1:                      # nothing grouped (the reference would crash here)
+            out["proposal_scores"] = (out["point_features"].new_zeros((0, 1)), proposals_idx, proposals_offset)
+            return out
+        vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"],
+                                         data_dict["point_xyz"], net.score_scale, net.score_fullscale, self.device,
+                                         rand=self.voxelization_rand)
+        score_feats = self.score_net(vox).features[p2v]                       # (sumNPoint, m)
+        pooled = common_ops.roipool(score_feats, proposals_offset)            # (nProposal, m)
+        out["proposal_scores"] = (self.score_branch(pooled), proposals_idx, proposals_offset)
+        return out
+
+    def _loss(self, data_dict, output_dict):
+        losses = super()._loss(data_dict, output_dict)
+        if "proposal_scores" in output_dict:
+            net = self.hparams.cfg.model.network
+            scores, proposals_idx, proposals_offset = output_dict["proposal_scores"]
+            if proposals_offset.numel() > 1:
+                ious = common_ops.get_iou(proposals_idx[:, 1].int().contiguous(), proposals_offset,
+                                          data_dict["instance_ids"], data_dict["instance_num_point"])
+                target = get_segmented_scores(ious.max(1)[0], net.fg_thresh, net.bg_thresh)
+                losses["score_loss"] = nn.functional.binary_cross_entropy_with_logits(scores.view(-1), target)
+            else:
+                losses["score_loss"] = scores.sum() * 0
+        return losses
