@@ -53,6 +53,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.lib()  # raises HipLibraryError when the .so is absent
         self.ws = _Workspace()
+        self.kernel_timer = None  # bench.py installs a KernelTimer to bracket chosen launches with HIP events
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -194,6 +195,41 @@ def _f32(t):
     return None if t is None else t.contiguous()
 
 
+class KernelTimer:
+    """brackets selected launches with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream) and keeps the algorithmic byte count of each (SURVEY 8d formula)"""
+
+    def __init__(self, select):
+        self.select = select            # (name, K, cin, cout) -> bool
+        self.records = []               # (start_event, end_event, algorithmic_bytes)
+        self._pairs = {}                # table data_ptr -> number of valid (in, out) pairs
+        self.enabled = False
+
+    def begin(self, name, K, cin, cout, nbr):
+        if not self.enabled or not self.select(name, K, cin, cout):
+            return None
+        key = (nbr.data_ptr(), nbr.numel())
+        if key not in self._pairs:
+            self._pairs[key] = int((nbr >= 0).sum().item())
+        nM = self._pairs[key]
+        nbytes = nM * (cin + cout) * 4 + nM * 8 + K * cin * cout * 4
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
+        ev[0].record()
+        return ev
+
+    def end(self, ev):
+        ev[1].record()
+        self.records.append(ev)
+
+    def summary(self):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b, _ in self.records]
+        nb = [n for _, _, n in self.records]
+        return dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_bytes=sum(nb) / len(nb))
+
+
 class _HipEngine:
     PARTIAL_ROWS = 1024
 
@@ -267,10 +303,14 @@ class _HipEngine:
             nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout))
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
             bnargs = [_f32(t) for t in bn_bwd]
+        timer = self.kernel_timer
+        tok = timer.begin("spconv_fwd", K, cin, cout, nbr) if timer is not None else None
         _lib.check(self.lib.ms3d_spconv_forward(
             _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
             _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
             *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), _lib.stream_handle()), "ms3d_spconv_forward")
+        if tok is not None:
+            timer.end(tok)
         if bn_bwd is None:
             return out
         s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)

@@ -9,10 +9,10 @@
  *
  * Pinning status: pg_bfs_cluster / sg_bfs_cluster / hierarchical_aggregation (CC+split)
  * are checked against the reference's own C++ (built into oracle/_ref, see
- * oracle/build_ref.sh) and against tests/golden/*.npz generated from it.  The GPU-only
+ * oracle/build_ref.py) and against the tests/golden fixtures generated from it.  The GPU-only
  * reference ops (ball query, segment ops, pools, IoU) are restated line by line from
  * the reference .cu files and cross-checked against the reference kernels themselves
- * when oracle/_ref runs on a GPU box (tests/test_ref_gpu.py).
+ * when oracle/_ref runs on a GPU box (tests/test_grouping_gpu.py::test_reference_gpu_kernels_agree).
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  Contraction is
  * OFF so that every fused multiply-add below is an explicit fmaf().
@@ -34,32 +34,48 @@
  *
  * Pass idx == NULL to only count.  Returns nActive = sum(len).  `cap` is the number of
  * ints available in idx; entries past it are dropped like bfs_cluster.cu:51-58.      */
+static int bq_one(int i, float r2, const float *xyz, const uint8_t *batch_idxs, const int *batch_offsets,
+                  int *out /* may be NULL */, long room)
+{
+    const float ox = xyz[i * 3 + 0], oy = xyz[i * 3 + 1], oz = xyz[i * 3 + 2];
+    const int b = batch_idxs[i];
+    const int s = batch_offsets[b], e = batch_offsets[b + 1]; /* :28-30 */
+    int cnt = 0;
+    for (int k = s; k < e; k++) { /* :32-46 */
+        const float dx = ox - xyz[k * 3 + 0];
+        const float dy = oy - xyz[k * 3 + 1];
+        const float dz = oz - xyz[k * 3 + 2];
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d2 < r2) {
+            if (cnt < BQ_CAP) {
+                if (out && cnt < room) out[cnt] = k;
+            } else
+                break;
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
 long orc_ballquery_batch_p(int n, float radius, const float *xyz, const uint8_t *batch_idxs,
                            const int *batch_offsets, int *idx, long cap, int *start_len)
 {
     const float r2 = radius * radius; /* bfs_cluster.cu:23 */
+    /* points are independent: the per-point scans run on all host cores, the canonical starts are the
+     * serial prefix sum of the counts */
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) start_len[i * 2 + 1] = bq_one(i, r2, xyz, batch_idxs, batch_offsets, NULL, 0);
     long cum = 0;
     for (int i = 0; i < n; i++) {
-        const float ox = xyz[i * 3 + 0], oy = xyz[i * 3 + 1], oz = xyz[i * 3 + 2];
-        const int b = batch_idxs[i];
-        const int s = batch_offsets[b], e = batch_offsets[b + 1]; /* :28-30 */
-        int cnt = 0;
-        for (int k = s; k < e; k++) { /* :32-46 */
-            const float dx = ox - xyz[k * 3 + 0];
-            const float dy = oy - xyz[k * 3 + 1];
-            const float dz = oz - xyz[k * 3 + 2];
-            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            if (d2 < r2) {
-                if (cnt < BQ_CAP) {
-                    if (idx && cum + cnt < cap) idx[cum + cnt] = k;
-                } else
-                    break;
-                ++cnt;
-            }
-        }
         start_len[i * 2 + 0] = (int)cum;
-        start_len[i * 2 + 1] = cnt;
-        cum += cnt;
+        cum += start_len[i * 2 + 1];
+    }
+    if (idx) {
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int i = 0; i < n; i++) {
+            const long st = start_len[i * 2];
+            if (st < cap) bq_one(i, r2, xyz, batch_idxs, batch_offsets, idx + st, cap - st);
+        }
     }
     return cum;
 }
