@@ -72,8 +72,10 @@ def cpu_baseline(cfg, n_points_budget):
     from oracle.oracle_backend import OracleBackend
     prev = ms_backend.set_backend(OracleBackend())
     try:
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)   # more threads only thrash on these loop sizes
         torch.set_num_threads(cores)
+        from oracle import oracle as O
+        O.lib().orc_set_threads(cores)
         dev = torch.device("cpu")
         model = build(cfg, dev)
         opt = model.configure_optimizers()

@@ -130,10 +130,12 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
                         const float *bn_mean, const float *bn_invstd, float *bn_partial, ms3d_stream_t stream);
-/* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:]  (dW zeroed here, float atomics across row chunks) */
+/* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs
+ * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
+int ms3d_spconv_wgrad_row_chunks(int Vout);
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
                                 int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
-                                ms3d_stream_t stream);
+                                float *partial_ws, ms3d_stream_t stream);
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */
 int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *scale, float *shift,

@@ -72,6 +72,9 @@ class HipBackend:
         start_len = torch.zeros((n, 2), dtype=torch.int32, device=dev)
         if n == 0:
             return torch.zeros(0, dtype=torch.int32, device=dev), start_len
+        if max_scene_points <= 0:
+            # tight per-scene bound -> smaller LDS bitmap, more waves per CU (the call syncs for nActive anyway)
+            max_scene_points = int((batch_offsets[1:] - batch_offsets[:-1]).max().item())
         ws_bytes = self.lib.ms3d_ballquery_workspace_bytes(n)
         ws = self.ws.get("bq", ws_bytes, dev)
         n_active = C.c_int(0)
@@ -322,9 +325,11 @@ class _HipEngine:
         x = self._dev(x); dout = self._dev(dout)
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
         ps, pb = (pre if pre is not None else (None, None))
+        chunks = self.lib.ms3d_spconv_wgrad_row_chunks(int(vout))
+        ws = self.ws.get("wgrad", chunks * K * cin * cout * 4, x.device)
         _lib.check(self.lib.ms3d_spconv_backward_weight(
             _lib.ptr(x), _lib.ptr(dout), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(dW),
-            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.stream_handle()),
+            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(ws), _lib.stream_handle()),
             "ms3d_spconv_backward_weight")
         return dW
 

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
             }
         }
         int nhits = 0;
+        int wlo = 0x7fffffff, whi = -1;  // bitmap words touched by this query (bitmap path only)
         for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + l;
             bool hit = false;
@@ -194,8 +195,12 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
             if (FILL && hit) {
                 if (small)
                     s_hits[nhits + ballot_rank(m)] = k;
-                else
-                    atomicOr(&s_bits[(k - sbeg) >> 5], 1u << ((k - sbeg) & 31));
+                else {
+                    const int w = (k - sbeg) >> 5;
+                    atomicOr(&s_bits[w], 1u << ((k - sbeg) & 31));
+                    wlo = min(wlo, w);
+                    whi = max(whi, w);
+                }
             }
             nhits += __popcll(m);
         }
@@ -219,9 +224,12 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
             // ordered emission of the first `my_len` set bits; lanes take interleaved words so runs of
             // consecutive indices spread over the wave
             int emitted = 0;
-            for (int w0 = 0; w0 < bitmap_words && emitted < my_len; w0 += 64) {
+            wlo = wave_min(wlo);
+            whi = -wave_min(-whi);
+            const int w_begin = wlo & ~63, w_end = whi + 1;   // only the touched word range is scanned and cleared
+            for (int w0 = w_begin; w0 < w_end && emitted < my_len; w0 += 64) {
                 const int w = w0 + l;
-                unsigned bits = (w < bitmap_words) ? s_bits[w] : 0u;
+                unsigned bits = (w < w_end) ? s_bits[w] : 0u;
                 if (__ballot(bits != 0u) == 0ull) continue;
                 const int pc = __popc(bits);
                 int rank = emitted + wave_incl_scan(pc) - pc;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
                     rank++;
                 }
             }
-            for (int w = l; w < bitmap_words; w += 64) s_bits[w] = 0u;  // leave the bitmap clean for the next query
+            for (int w = w_begin + l; w < w_end; w += 64) s_bits[w] = 0u;  // leave the bitmap clean for the next query
         }
         __builtin_amdgcn_wave_barrier();
     }

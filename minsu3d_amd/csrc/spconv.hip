@@ -260,20 +260,22 @@ struct WgradArgs {
     const float *in;         // [Vin, Cin]
     const float *dout;       // [Vout, Cout]
     const int *nbr;          // [K][Vout]
-    float *dW;               // [K, Cin, Cout], pre-zeroed, accumulated with float atomics
+    float *partial;          // [gridDim.x][K, Cin, Cout] per-row-chunk partial sums (reduced by a second kernel)
     const float *pre_scale;  // fused BN(+ReLU) on `in` (recomputed), or null
     const float *pre_shift;
     int Vout, K, Cin, Cout, NBtot, rows_per_block, pre_relu;
 };
 
-// grid: x = row chunk, y = offset group (KG offsets), z = 16-channel input chunk
+// grid: x = row chunk, y = offset group (KG offsets), z = 16-channel input chunk.  Rows are the MFMA reduction
+// dimension (4 per instruction).  All KG neighbour indices, then all KG gathers, are issued before the first
+// MFMA so a wave keeps ~KG loads in flight; the KG offsets share the dout fragment.
 template <int KG, int NBT>
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
 {
-    __shared__ float s_red[4][64];  // cross-wave reduction scratch (one fragment at a time)
+    __shared__ float s_red[3][64 * 4];  // waves 1..3 hand one accumulator (4 regs x 64 lanes) to wave 0
     const int l = lane_id(), q = l >> 4, cl = l & 15;
     const int k0 = blockIdx.y * KG;
-    const int c = blockIdx.z * 16 + cl;      // input channel owned by this lane's A element
+    const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A element
     const bool c_ok = c < p.Cin;
     const float sc = (p.pre_scale && c_ok) ? p.pre_scale[c] : 1.f;
     const float sh = (p.pre_scale && c_ok) ? p.pre_shift[c] : 0.f;
@@ -285,60 +287,85 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
 
     const int r_begin = blockIdx.x * p.rows_per_block;
     const int r_end = min(p.Vout, r_begin + p.rows_per_block);
-    for (int r0 = r_begin + wave_id() * 4; r0 < r_end; r0 += 4 * (blockDim.x >> 6)) {
+    const int nw = blockDim.x >> 6;
+    for (int r0 = r_begin + wave_id() * 4; r0 < r_end; r0 += 4 * nw) {
         const int row = r0 + q;  // k-slot q of the MFMA <-> row r0 + q
         const bool row_ok = row < r_end;
         float b[NBT];
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++)
             b[nb] = (row_ok && 16 * nb + cl < p.Cout) ? p.dout[(size_t)row * p.Cout + 16 * nb + cl] : 0.f;
+        int idx[KG];
+#pragma unroll
+        for (int kk = 0; kk < KG; kk++)
+            idx[kk] = (k0 + kk < p.K && row_ok) ? p.nbr[(size_t)(k0 + kk) * p.Vout + row] : -1;
+        float a[KG];
 #pragma unroll
         for (int kk = 0; kk < KG; kk++) {
-            const int k = k0 + kk;
-            int idx = -1;
-            if (k < p.K && row_ok) idx = p.nbr[(size_t)k * p.Vout + row];
-            if (__ballot(idx >= 0) == 0ull) continue;
-            float a = 0.f;
-            if (idx >= 0 && c_ok) {
-                a = p.in[(size_t)idx * p.Cin + c];
+            a[kk] = 0.f;
+            if (idx[kk] >= 0 && c_ok) {
+                float v = p.in[(size_t)idx[kk] * p.Cin + c];
                 if (p.pre_scale) {
-                    a = fmaf(a, sc, sh);
-                    if (p.pre_relu) a = fmaxf(a, 0.f);
+                    v = fmaf(v, sc, sh);
+                    if (p.pre_relu) v = fmaxf(v, 0.f);
                 }
+                a[kk] = v;
             }
+        }
 #pragma unroll
-            for (int nb = 0; nb < NBT; nb++) acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nb], acc[kk][nb], 0, 0, 0);
+        for (int kk = 0; kk < KG; kk++) {
+            if (__ballot(idx[kk] >= 0) == 0ull) continue;
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b[nb], acc[kk][nb], 0, 0, 0);
         }
     }
-    // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl
-    const int nw = blockDim.x >> 6;
+    // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl.
+    // Sum the block's waves through LDS in a fixed order, then one plain store per element per block.
+    float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
 #pragma unroll
     for (int kk = 0; kk < KG; kk++) {
         const int k = k0 + kk;
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++) {
+            __syncthreads();
+            if (wave_id() > 0) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                // sum the waves of this block in LDS first: one global atomic per element per block
-                __syncthreads();
-                s_red[wave_id()][l] = acc[kk][nb][r];
-                __syncthreads();
-                if (wave_id() == 0) {
-                    float v = 0.f;
-                    for (int w = 0; w < nw; w++) v += s_red[w][l];
+                for (int r = 0; r < 4; r++) s_red[wave_id() - 1][r * 64 + l] = acc[kk][nb][r];
+            }
+            __syncthreads();
+            if (wave_id() == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[kk][nb][r];
+                    for (int w = 1; w < nw; w++) v += s_red[w - 1][r * 64 + l];
                     const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
-                    if (k < p.K && ci < p.Cin && j < p.Cout && v != 0.f)
-                        atomicAdd(&p.dW[((size_t)k * p.Cin + ci) * p.Cout + j], v);
+                    if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
                 }
             }
         }
     }
 }
 
-template <int KG, int NBT>
-int launch_wgrad(const WgradArgs &p, hipStream_t stream)
+// dW[e] = sum over row chunks of partial[b][e], fixed order -> deterministic
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int nblk, long n, float *__restrict__ dW)
 {
-    const int nblk_rows = ms3d_divup(p.Vout, p.rows_per_block);
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[(size_t)b * n + e];
+        s1 += partial[(size_t)(b + 1) * n + e];
+        s2 += partial[(size_t)(b + 2) * n + e];
+        s3 += partial[(size_t)(b + 3) * n + e];
+    }
+    for (; b < nblk; b++) s0 += partial[(size_t)b * n + e];
+    dW[e] = (s0 + s1) + (s2 + s3);
+}
+
+template <int KG, int NBT>
+int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
+{
     dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
     spconv_wgrad_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
     MS3D_LAUNCH_CHECK();
@@ -346,19 +373,32 @@ int launch_wgrad(const WgradArgs &p, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------ BN helper kernels
-// column sums over a [nparts][2][C] partial buffer -> mean / invstd / scale / shift (+ running stats)
-__global__ void bn_finalize_stats_kernel(const float *__restrict__ partial, int nparts, int C, long V, float eps,
-                                         float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                         float *running_mean, float *running_var, float *__restrict__ mean_out,
-                                         float *__restrict__ invstd_out, float *__restrict__ scale_out,
-                                         float *__restrict__ shift_out)
+// column sums over a [nparts][2][C] partial buffer -> mean / invstd / scale / shift (+ running stats).
+// One block per 16 channels; 16 part-lanes per channel sum in double, combined in a fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_stats_kernel(const float *__restrict__ partial, int nparts, int C, long V,
+                                                                float eps, float momentum, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float *running_mean,
+                                                                float *running_var, float *__restrict__ mean_out,
+                                                                float *__restrict__ invstd_out, float *__restrict__ scale_out,
+                                                                float *__restrict__ shift_out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double s_1[16][17], s_2[16][17];
+    const int cl = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int p = lp; p < nparts; p += 16) {
+            a1 += (double)partial[((size_t)p * 2 + 0) * C + c];
+            a2 += (double)partial[((size_t)p * 2 + 1) * C + c];
+        }
+    s_1[lp][cl] = a1;
+    s_2[lp][cl] = a2;
+    __syncthreads();
+    if (threadIdx.x >= 16 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < nparts; p++) {
-        s1 += (double)partial[((size_t)p * 2 + 0) * C + c];
-        s2 += (double)partial[((size_t)p * 2 + 1) * C + c];
+    for (int i = 0; i < 16; i++) {
+        s1 += s_1[i][cl];
+        s2 += s_2[i][cl];
     }
     const double mean = s1 / (double)V;
     double var = s2 / (double)V - mean * mean;  // biased, as torch BatchNorm uses for normalisation
@@ -376,7 +416,8 @@ __global__ void bn_finalize_stats_kernel(const float *__restrict__ partial, int 
     }
 }
 
-// per-block partial (sum, sum of squares) per channel; rows striped over blocks, lanes over channels
+// per-block partial (sum, sum of squares) per channel.  Each thread streams float4s (C % 4 == 0) of the block's
+// contiguous row range: fully coalesced 16 B/lane, 4 loads in flight per thread.
 __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float *__restrict__ x, long V, int C,
                                                                float *__restrict__ partial, int rows_per_block)
 {
@@ -385,28 +426,38 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float *__re
     __syncthreads();
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(V, r_begin + rows_per_block);
-    // thread t handles flat elements t, t+256, ... of the block's row range: fully coalesced
     const long e_begin = r_begin * C, e_end = r_end * C;
-    const int step = blockDim.x;
-    {
-        // channel of element e is e % C; accumulate privately when the channel is loop invariant
-        if (step % C == 0) {
-            const int c = threadIdx.x % C;
-            float s1 = 0.f, s2 = 0.f;
-            for (long e = e_begin + threadIdx.x; e < e_end; e += step) {
-                const float v = x[e];
-                s1 += v;
-                s2 = fmaf(v, v, s2);
+    if ((C & 3) == 0) {
+        const long v_begin = e_begin >> 2, v_end = e_end >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        if ((4 * 256) % C == 0) {
+            // the channel group of a thread never changes: accumulate in registers
+            const int c = (int)((4 * (v_begin + threadIdx.x)) % C);
+            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+            for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
+                const float4 t = x4[v];
+                s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
+                s2.x = fmaf(t.x, t.x, s2.x); s2.y = fmaf(t.y, t.y, s2.y); s2.z = fmaf(t.z, t.z, s2.z); s2.w = fmaf(t.w, t.w, s2.w);
             }
-            atomicAdd(&s_acc[c], s1);
-            atomicAdd(&s_acc[C + c], s2);
+            atomicAdd(&s_acc[c + 0], s1.x); atomicAdd(&s_acc[c + 1], s1.y); atomicAdd(&s_acc[c + 2], s1.z); atomicAdd(&s_acc[c + 3], s1.w);
+            atomicAdd(&s_acc[C + c + 0], s2.x); atomicAdd(&s_acc[C + c + 1], s2.y); atomicAdd(&s_acc[C + c + 2], s2.z); atomicAdd(&s_acc[C + c + 3], s2.w);
         } else {
-            for (long e = e_begin + threadIdx.x; e < e_end; e += step) {
-                const float v = x[e];
-                const int c = (int)(e % C);
-                atomicAdd(&s_acc[c], v);
-                atomicAdd(&s_acc[C + c], v * v);
+#pragma unroll 2
+            for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
+                const float4 t = x4[v];
+                const int c = (int)((4 * v) % C);
+                atomicAdd(&s_acc[c + 0], t.x); atomicAdd(&s_acc[c + 1], t.y); atomicAdd(&s_acc[c + 2], t.z); atomicAdd(&s_acc[c + 3], t.w);
+                atomicAdd(&s_acc[C + c + 0], t.x * t.x); atomicAdd(&s_acc[C + c + 1], t.y * t.y);
+                atomicAdd(&s_acc[C + c + 2], t.z * t.z); atomicAdd(&s_acc[C + c + 3], t.w * t.w);
             }
+        }
+    } else {
+        for (long e = e_begin + threadIdx.x; e < e_end; e += 256) {
+            const float v = x[e];
+            const int c = (int)(e % C);
+            atomicAdd(&s_acc[c], v);
+            atomicAdd(&s_acc[C + c], v * v);
         }
     }
     __syncthreads();
@@ -465,13 +516,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
     for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];
 }
 
-__global__ void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n, float *__restrict__ out)
+// out[t] = sum_p partial[p][t]: 16 columns x 16 part-lanes per block, fixed combination order
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n,
+                                                             float *__restrict__ out)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    __shared__ double s_sum[16][17];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane_p = threadIdx.x >> 4;
     double s = 0.0;
-    for (int p = 0; p < nparts; p++) s += (double)partial[(size_t)p * n + t];
-    out[t] = (float)s;
+    if (col < n)
+        for (int p = lane_p; p < nparts; p += 16) s += (double)partial[(size_t)p * n + col];
+    s_sum[lane_p][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < n) {
+        double t = 0.0;
+        for (int i = 0; i < 16; i++) t += s_sum[i][threadIdx.x];
+        out[col] = (float)t;
+    }
 }
 
 }  // namespace
@@ -560,34 +620,49 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     return MS3D_E_UNSUPPORTED;
 }
 
+int ms3d_spconv_wgrad_row_chunks(int Vout)
+{
+    // ~2048+ waves in flight at full resolution, at most 512 partial slabs
+    int chunks = ms3d_divup(Vout, 256);
+    if (chunks > 512) chunks = 512;
+    return chunks < 1 ? 1 : chunks;
+}
+
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                 float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
-                                ms3d_stream_t stream_)
+                                float *partial_ws, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, stream));
-    if (Vout <= 0) return 0;
+    const long n = (long)K * Cin * Cout;
+    if (Vout <= 0) {
+        MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * n, stream));
+        return 0;
+    }
     WgradArgs p;
-    p.in = in; p.dout = dout; p.nbr = nbr; p.dW = dW; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+    p.in = in; p.dout = dout; p.nbr = nbr; p.partial = partial_ws; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = ms3d_divup(Cout, 16); p.pre_relu = pre_relu;
-    // enough row chunks to fill the chip, but each long enough to amortise the final reduction
-    int chunks = ms3d_divup(Vout, 2048);
-    if (chunks > 512) chunks = 512;
+    const int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
     p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
+    const int nblk = ms3d_divup(Vout, p.rows_per_block);
     const int nb = p.NBtot;
     if (nb > 14) return MS3D_E_UNSUPPORTED;
+    int rc;
     // KG * NBT <= 28 accumulators of 4 VGPRs
-    if (nb == 1) return (K >= 27) ? launch_wgrad<27, 1>(p, stream) : launch_wgrad<8, 1>(p, stream);
-    if (nb == 2) return (K >= 27) ? launch_wgrad<9, 2>(p, stream) : launch_wgrad<8, 2>(p, stream);
-    if (nb == 3) return (K >= 27) ? launch_wgrad<9, 3>(p, stream) : launch_wgrad<8, 3>(p, stream);
-    if (nb == 4) return launch_wgrad<4, 4>(p, stream);
-    if (nb == 5) return launch_wgrad<4, 5>(p, stream);
-    if (nb == 6) return launch_wgrad<4, 6>(p, stream);
-    if (nb == 7) return launch_wgrad<4, 7>(p, stream);
-    if (nb == 8) return launch_wgrad<3, 8>(p, stream);
-    if (nb <= 10) return launch_wgrad<2, 10>(p, stream);
-    if (nb <= 12) return launch_wgrad<2, 12>(p, stream);
-    return launch_wgrad<2, 14>(p, stream);
+    if (nb == 1) rc = (K >= 27) ? launch_wgrad<27, 1>(p, nblk, stream) : launch_wgrad<8, 1>(p, nblk, stream);
+    else if (nb == 2) rc = (K >= 27) ? launch_wgrad<9, 2>(p, nblk, stream) : launch_wgrad<8, 2>(p, nblk, stream);
+    else if (nb == 3) rc = (K >= 27) ? launch_wgrad<9, 3>(p, nblk, stream) : launch_wgrad<8, 3>(p, nblk, stream);
+    else if (nb == 4) rc = launch_wgrad<4, 4>(p, nblk, stream);
+    else if (nb == 5) rc = launch_wgrad<4, 5>(p, nblk, stream);
+    else if (nb == 6) rc = launch_wgrad<4, 6>(p, nblk, stream);
+    else if (nb == 7) rc = launch_wgrad<4, 7>(p, nblk, stream);
+    else if (nb == 8) rc = launch_wgrad<3, 8>(p, nblk, stream);
+    else if (nb <= 10) rc = launch_wgrad<2, 10>(p, nblk, stream);
+    else if (nb <= 12) rc = launch_wgrad<2, 12>(p, nblk, stream);
+    else rc = launch_wgrad<2, 14>(p, nblk, stream);
+    if (rc) return rc;
+    wgrad_reduce_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(partial_ws, nblk, n, dW);
+    MS3D_LAUNCH_CHECK();
+    return 0;
 }
 
 // training-mode batch statistics of x [V, C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale,
@@ -598,13 +673,13 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (V <= 0) return MS3D_E_UNSUPPORTED;
-    int nblk = (int)((V + 1023) / 1024);
+    int nblk = (int)((V + 255) / 256);
     if (nblk > partial_rows) nblk = partial_rows;
     if (nblk < 1) nblk = 1;
     const int rows_per_block = (int)((V + nblk - 1) / nblk);
     bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
     MS3D_LAUNCH_CHECK();
-    bn_finalize_stats_kernel<<<ms3d_divup(C, 64), 64, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
+    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 256, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
                                                                   running_mean, running_var, mean, invstd, scale, shift);
     MS3D_LAUNCH_CHECK();
     return 0;
@@ -624,7 +699,7 @@ int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float
 // s1s2 [2][C] = column sums of a [nparts][2][C] partial buffer (fixed order -> deterministic)
 int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream)
 {
-    reduce_partial_kernel<<<ms3d_divup(n, 64), 64, 0, (hipStream_t)stream>>>(partial, nparts, n, out);
+    reduce_partial_kernel<<<ms3d_divup(n, 16), 256, 0, (hipStream_t)stream>>>(partial, nparts, n, out);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

@@ -30,7 +30,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <omp.h>
 typedef uint64_t u64;
+
+/* bound the OpenMP team (hosts with hundreds of cores thrash on these short loops) */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 static inline u64 pack_key(int b, int x, int y, int z)
 {

@@ -46,11 +46,14 @@ def test_pointgroup_step_hip_vs_oracle():
     assert rel(out_h["semantic_scores"], out_r["semantic_scores"]) < 2e-3
     assert rel(out_h["proposal_scores"][0], out_r["proposal_scores"][0]) < 5e-3
     for k in loss_r:
-        assert abs(float(loss_h[k]) - float(loss_r[k])) < 2e-3 * max(1.0, abs(float(loss_r[k]))), k
+        assert abs(float(loss_h[k].detach()) - float(loss_r[k].detach())) < 2e-3 * max(1.0, abs(float(loss_r[k].detach()))), k
     gr = dict(ref_model.named_parameters())
     for n, p in hip_model.named_parameters():
         if gr[n].grad is None:
             assert p.grad is None
+            continue
+        if gr[n].grad.abs().max() < 1e-6:      # mathematically zero (e.g. a Linear bias in front of BatchNorm1d)
+            assert p.grad.abs().max() < 1e-5, n
             continue
         assert rel(p.grad, gr[n].grad) < 3e-2, n
 
