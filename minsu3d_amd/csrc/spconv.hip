@@ -78,22 +78,42 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
 }
 
 // ------------------------------------------------------------------ forward / backward-data
+constexpr int OG = 9;  // offsets processed together: 9 neighbour indices, then 9 row gathers in flight per wave
+
+// Offsets [k_lo, k_hi) of one 16-row tile.  `kw0` = index of offset k_lo inside the LDS weight image.
+// Loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
+// compiler drain vmcnt(0) before each one, which serialises the whole neighbourhood (measured: 27 x latency).
 template <int NBT, bool ALIGNED>
-__device__ __forceinline__ void accumulate_offset(const ConvArgs &p, const float *__restrict__ sW, int kk, int idx,
-                                                  int q, int nb0, f32x4 (&acc)[NBT])
+__device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const float *__restrict__ sW, int k_lo, int k_hi,
+                                                   int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
 {
     const int l = lane_id();
-    for (int ch = 0; ch < p.NCH; ch++) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        const int c0 = 16 * ch + 4 * q;
-        if (idx >= 0) {
-            const float *row = p.in + (size_t)idx * p.Cin + c0;
-            if (ALIGNED) {
-                a = *reinterpret_cast<const f32x4 *>(row);
-            } else {
+    const bool row_ok = my_row < p.Vout;
+    const int safe_row = row_ok ? my_row : 0;
+    for (int g0 = k_lo; g0 < k_hi; g0 += OG) {
+        int idx[OG];
 #pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (c0 + t < p.Cin) a[t] = row[t];
+        for (int u = 0; u < OG; u++) {
+            const int k = min(g0 + u, k_hi - 1);
+            // OR-mask instead of a select: a select lets the compiler sink the load into a branch + vmcnt(0)
+            const int v = p.nbr[(size_t)k * p.Vout + safe_row];
+            idx[u] = v | ((row_ok && g0 + u < k_hi) ? 0 : -1);
+        }
+        bool any[OG];
+#pragma unroll
+        for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
+        for (int ch = 0; ch < p.NCH; ch++) {
+            const int c0 = 16 * ch + 4 * q;
+            f32x4 a[OG];
+#pragma unroll
+            for (int u = 0; u < OG; u++) {
+                const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
+                if (ALIGNED) {
+                    a[u] = *reinterpret_cast<const f32x4 *>(row);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) a[u][t] = (c0 + t < p.Cin) ? row[t] : 0.f;
+                }
             }
             if (p.pre_scale) {
                 f32x4 s, b;
@@ -108,18 +128,27 @@ __device__ __forceinline__ void accumulate_offset(const ConvArgs &p, const float
                     }
                 }
 #pragma unroll
+                for (int u = 0; u < OG; u++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float v = fmaf(a[u][t], s[t], b[t]);
+                        a[u][t] = p.pre_relu ? fmaxf(v, 0.f) : v;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < OG; u++) {
+                const int keep = ~(idx[u] >> 31);  // absent neighbour (idx < 0) contributes nothing
+#pragma unroll
+                for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
+                if (!any[u]) continue;                                  // wave-uniform: none of the 16 rows has it
+                const float *w = sW + ((size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+#pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    float v = fmaf(a[t], s[t], b[t]);
-                    a[t] = p.pre_relu ? fmaxf(v, 0.f) : v;
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
                 }
             }
-        }
-        const float *w = sW + ((size_t)((kk * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-#pragma unroll
-            for (int nb = 0; nb < NBT; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
         }
     }
 }
@@ -198,11 +227,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             f32x4 acc[NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < p.K; k++) {
-                const int idx = (my_row < p.Vout) ? p.nbr[(size_t)k * p.Vout + my_row] : -1;
-                if (__ballot(idx >= 0) == 0ull) continue;
-                accumulate_offset<NBT, ALIGNED>(p, sW, k, idx, q, nb0, acc);
-            }
+            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
             store_tile<NBT>(p, row0, nb0, acc, s_part);
         }
     } else {
@@ -219,13 +244,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wf + per_offset * g0);
             for (size_t t = threadIdx.x; t < per_offset * gn / 4; t += blockDim.x) reinterpret_cast<f32x4 *>(sW)[t] = src[t];
             __syncthreads();
-            if (tile < p.ntiles) {
-                for (int kk = 0; kk < gn; kk++) {
-                    const int idx = (my_row < p.Vout) ? p.nbr[(size_t)(g0 + kk) * p.Vout + my_row] : -1;
-                    if (__ballot(idx >= 0) == 0ull) continue;
-                    accumulate_offset<NBT, ALIGNED>(p, sW, kk, idx, q, nb0, acc);
-                }
-            }
+            if (tile < p.ntiles) accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, q, nb0, acc);
         }
         if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
@@ -277,6 +296,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     const int k0 = blockIdx.y * KG;
     const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A element
     const bool c_ok = c < p.Cin;
+    const int c_safe = c_ok ? c : 0;
+    const int c_mask = c_ok ? -1 : 0;
     const float sc = (p.pre_scale && c_ok) ? p.pre_scale[c] : 1.f;
     const float sh = (p.pre_scale && c_ok) ? p.pre_shift[c] : 0.f;
     f32x4 acc[KG][NBT];
@@ -293,24 +314,30 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
         const bool row_ok = row < r_end;
         float b[NBT];
 #pragma unroll
-        for (int nb = 0; nb < NBT; nb++)
-            b[nb] = (row_ok && 16 * nb + cl < p.Cout) ? p.dout[(size_t)row * p.Cout + 16 * nb + cl] : 0.f;
+        for (int nb = 0; nb < NBT; nb++) {
+            const int j = 16 * nb + cl;
+            const float v = p.dout[(size_t)(row_ok ? row : r_begin) * p.Cout + (j < p.Cout ? j : 0)];
+            b[nb] = __int_as_float(__float_as_int(v) & ((row_ok && j < p.Cout) ? -1 : 0));
+        }
+        // unconditional loads (clamped addresses, values zeroed afterwards) so all KG gathers are in flight together
+        const int safe_row = row_ok ? row : r_begin;
         int idx[KG];
 #pragma unroll
-        for (int kk = 0; kk < KG; kk++)
-            idx[kk] = (k0 + kk < p.K && row_ok) ? p.nbr[(size_t)(k0 + kk) * p.Vout + row] : -1;
+        for (int kk = 0; kk < KG; kk++) {
+            const int v = p.nbr[(size_t)min(k0 + kk, p.K - 1) * p.Vout + safe_row];
+            idx[kk] = v | ((k0 + kk < p.K && row_ok) ? 0 : -1);
+        }
         float a[KG];
 #pragma unroll
+        for (int kk = 0; kk < KG; kk++) a[kk] = p.in[(size_t)max(idx[kk], 0) * p.Cin + c_safe];
+#pragma unroll
         for (int kk = 0; kk < KG; kk++) {
-            a[kk] = 0.f;
-            if (idx[kk] >= 0 && c_ok) {
-                float v = p.in[(size_t)idx[kk] * p.Cin + c];
-                if (p.pre_scale) {
-                    v = fmaf(v, sc, sh);
-                    if (p.pre_relu) v = fmaxf(v, 0.f);
-                }
-                a[kk] = v;
+            float v = a[kk];
+            if (p.pre_scale) {
+                v = fmaf(v, sc, sh);
+                if (p.pre_relu) v = fmaxf(v, 0.f);
             }
+            a[kk] = __int_as_float(__float_as_int(v) & ~(idx[kk] >> 31) & c_mask);
         }
 #pragma unroll
         for (int kk = 0; kk < KG; kk++) {
@@ -564,7 +591,9 @@ int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
     const int ntiles = ms3d_divup(Vout, 16);
     int nblk;
     if (resident) {
-        nblk = ms3d_divup(ntiles, 4);
+        const size_t need = per_offset * K + 2 * Cout * sizeof(float);
+        const int threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
+        nblk = ms3d_divup(ntiles, threads / 64);
         if (nblk > 1024) nblk = 1024;
     } else
         nblk = ms3d_divup(ntiles, 16);
@@ -594,8 +623,10 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     int threads, nblk;
     if (resident) {
         p.G = K;
-        threads = 256;
-        nblk = ms3d_divup(p.ntiles, 4);
+        // keep >= 16 waves per CU whatever the LDS footprint of the weight image is
+        const size_t need = per_offset * K + extra;
+        threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
+        nblk = ms3d_divup(p.ntiles, threads / 64);
         if (nblk > 1024) nblk = 1024;
     } else {
         p.G = (int)((LDS_BUDGET - extra) / per_offset);
