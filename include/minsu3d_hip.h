@@ -46,10 +46,10 @@ int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz
  * the 1000-neighbour cap bites.  cluster_idxs has capacity [N,2], cluster_offsets [N+1];
  * counts[0] = nCluster, counts[1] = sumNPoint are returned to the [host]. */
 size_t ms3d_bfs_workspace_bytes(int N);
-int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, const int *start_len, int N,
-                        int threshold, int *cluster_idxs, int *cluster_offsets, int *counts /*[host,2]*/,
+int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, long n_edges /* = nActive */,
+                        const int *start_len, int N, int threshold, int *cluster_idxs, int *cluster_offsets, int *counts /*[host,2]*/,
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
-int ms3d_sg_bfs_cluster(const float *class_numpoint_mean /*[host]*/, const int *ball_query_idxs,
+int ms3d_sg_bfs_cluster(const float *class_numpoint_mean /*[host]*/, const int *ball_query_idxs, long n_edges,
                         const int *start_len, int N, float threshold, int class_id, int *cluster_idxs,
                         int *cluster_offsets, int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes,
                         ms3d_stream_t stream);

@@ -100,7 +100,8 @@ class HipBackend:
         ws_bytes = self.lib.ms3d_bfs_workspace_bytes(N)
         ws = self.ws.get("bfs", ws_bytes, dev)
         counts = (C.c_int * 2)(0, 0)
-        rc = getattr(self.lib, fn_name)(*args_head, _lib.ptr(ball_idx), _lib.ptr(start_len), N, *args_tail,
+        rc = getattr(self.lib, fn_name)(*args_head, _lib.ptr(ball_idx), C.c_long(ball_idx.numel()), _lib.ptr(start_len), N,
+                                        *args_tail,
                                         _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), counts, _lib.ptr(ws),
                                         C.c_size_t(ws.numel()), _lib.stream_handle())
         _lib.check(rc, fn_name)

@@ -104,13 +104,17 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int
 
 // roots go to their own array: concurrent path halving may still rewrite parent[] entries with
 // non-root ancestors while this kernel runs
-__global__ void bfs_flatten_kernel(int N, int *parent, int *root, int *comp_size)
+__global__ void bfs_flatten_kernel(int N, int *parent, int *root, int *comp_size, const int *__restrict__ start_len,
+                                   int *counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int r = uf_find(parent, i);
     root[i] = r;
     atomicAdd(&comp_size[r], 1);
+    // a list cut at the cap makes the graph directed (bfs_cluster.cu:38-43): only then can a weak component
+    // hold more than one cluster, and only then is the order-by-replay kernel required
+    if (start_len[i * 2 + 1] >= 1000 && counters[5] == 0) atomicOr(&counters[5], 1);
 }
 
 __global__ void bfs_select_kernel(int N, Thr thr, const int *__restrict__ root, const int *__restrict__ comp_size,
@@ -273,6 +277,134 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Chip-wide level-synchronous expansion for SYMMETRIC graphs (no list reached the cap): then a weak component is
+// exactly one cluster, seeded by its root, and all qualifying components can be expanded together by every CU.
+// The frontier array F holds, per level, each component's frontier as one contiguous segment in queue order.
+//   A  : node at frontier position p is assigned its final queue slot and posts atomicMin(claim[j], p) on every
+//        label-compatible neighbour that is not yet visited (visited <=> claim == -1);
+//   U  : per component: done += size of this level's segment, reset the segment bookkeeping;
+//   B1 : cnt[p] = number of edges of p that won (claim[j] == p);  scan -> off[p];
+//   B2 : winners written to F_next[off[p] + rank] in (p, slot) order, marked visited; the first winner of p
+//        lowers its component's next segment start.  Compaction in p order keeps segments contiguous and in
+//        exactly the order in which the serial FIFO BFS would have pushed the nodes.
+// glob counters: [6] |F| of even levels  [7] |F| of odd levels
+__global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__restrict__ comp_size, int *counters,
+                                 int *F0, int *comp_base, int *done, int *seg_start, int *seg_cnt, int *claim)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nwork = counters[0];
+    if (w == 0) counters[6] = nwork;
+    if (w >= nwork) return;
+    const int r = worklist[w];
+    F0[w] = r;
+    comp_base[r] = atomicAdd(&counters[2], comp_size[r]);
+    done[r] = 0;
+    seg_start[r] = w;
+    seg_cnt[r] = 1;
+    claim[r] = -1;  // the seed is visited
+}
+
+__global__ __launch_bounds__(256) void glob_claim_kernel(Thr thr, const int16_t *__restrict__ sem,
+                                                         const int *__restrict__ ball_idx,
+                                                         const int *__restrict__ start_len,
+                                                         const int *__restrict__ root, const int *__restrict__ F,
+                                                         const int *__restrict__ nF_ptr,
+                                                         const int *__restrict__ comp_base,
+                                                         const int *__restrict__ done,
+                                                         const int *__restrict__ seg_start, int *claim,
+                                                         int *scratch_node, int *scratch_seed)
+{
+    const int nF = *nF_ptr;
+    const int waves = blockDim.x >> 6, l = lane_id();
+    for (int p = blockIdx.x * waves + wave_id(); p < nF; p += gridDim.x * waves) {
+        const int node = F[p];
+        const int r = root[node];
+        if (l == 0) {
+            const int qpos = comp_base[r] + done[r] + (p - seg_start[r]);
+            scratch_node[qpos] = node;
+            scratch_seed[qpos] = r;
+        }
+        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
+        const int lab = thr.mode == 0 ? (int)sem[node] : 0;
+        for (int t = l; t < ln; t += 64) {
+            const int j = ball_idx[st + t];
+            if (thr.mode == 0 && (int)sem[j] != lab) continue;
+            if (claim[j] > p) atomicMin(&claim[j], p);  // stale reads are only ever too large -> a redundant atomic
+        }
+    }
+}
+
+__global__ void glob_update_kernel(const int *__restrict__ worklist, const int *__restrict__ counters, int *done,
+                                   int *seg_start, int *seg_cnt)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= counters[0]) return;
+    const int r = worklist[w];
+    done[r] += seg_cnt[r];
+    seg_cnt[r] = 0;
+    seg_start[r] = INT_BIG;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void glob_win_kernel(int N, const int *__restrict__ ball_idx,
+                                                       const int *__restrict__ start_len,
+                                                       const int *__restrict__ root, const int *__restrict__ F,
+                                                       const int *__restrict__ nF_ptr, int *claim, int *cnt,
+                                                       const int *__restrict__ off, int *F_next, int *seg_start,
+                                                       int *seg_cnt)
+{
+    const int nF = *nF_ptr;
+    const int waves = blockDim.x >> 6, l = lane_id();
+    const int limit = EMIT ? nF : N;  // the count pass also zeroes cnt[] beyond the frontier for the scan
+    for (int p = blockIdx.x * waves + wave_id(); p < limit; p += gridDim.x * waves) {
+        if (p >= nF) {
+            if (l == 0) cnt[p] = 0;
+            continue;
+        }
+        const int node = F[p];
+        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
+        int total = 0;
+        const int base = EMIT ? off[p] : 0;
+        for (int t0 = 0; t0 < ln; t0 += 64) {
+            const int t = t0 + l;
+            int j = -1;
+            bool win = false;
+            if (t < ln) {
+                j = ball_idx[st + t];
+                win = claim[j] == p;
+            }
+            const unsigned long long m = __ballot(win);
+            if (EMIT && win) {
+                F_next[base + total + ballot_rank(m)] = j;
+                claim[j] = -1;  // visited
+            }
+            total += __popcll(m);
+        }
+        if (l == 0) {
+            if (!EMIT) {
+                cnt[p] = total;
+            } else if (total > 0) {
+                const int r = root[node];
+                atomicMin(&seg_start[r], base);
+                atomicAdd(&seg_cnt[r], total);
+            }
+        }
+    }
+}
+
+// one cluster per qualifying component: seed = root, size = component size, members at comp_base
+__global__ void glob_finish_kernel(const int *__restrict__ worklist, const int *__restrict__ counters,
+                                   const int *__restrict__ comp_size, const int *__restrict__ comp_base, int *cl_size,
+                                   int *cl_start)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= counters[0]) return;
+    const int r = worklist[w];
+    cl_size[r] = comp_size[r];
+    cl_start[r] = comp_base[r];
+}
+
 __global__ void bfs_keep_kernel(int N, Thr thr, const int *__restrict__ cl_size, int *keep, int *keep_size)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,7 +438,7 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
 
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
-        *keep_size, *cid, *out_off, *counters;
+        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *cnt, *comp_base, *done, *seg_start, *seg_cnt;
     void *scan_ws;
 };
 size_t carve(BfsWorkspace &w, int N, void *base)
@@ -321,12 +453,15 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.parent = take(nb); w.root = take(nb); w.comp_size = take(nb); w.visited = take(nb); w.claim = take(nb); w.worklist = take(nb);
     w.scratch_node = take(nb); w.scratch_seed = take(nb); w.cl_size = take(nb); w.cl_start = take(nb);
     w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
+    // the chip-wide expansion reuses buffers that are idle until the assembly phase
+    w.Fa = w.keep; w.Fb = w.keep_size; w.cnt = w.cid; w.done = w.out_off;
+    w.comp_base = take(nb); w.seg_start = take(nb); w.seg_cnt = take(nb);
     w.counters = take(sizeof(int) * 8);
     w.scan_ws = take(ms3d_scan_workspace_bytes());
     return off;
 }
 
-int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, const int *start_len, int N, int *cluster_idxs,
+int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, const int *start_len, int N, int *cluster_idxs,
             int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     counts[0] = counts[1] = 0;
@@ -341,14 +476,63 @@ int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, const int *start_l
     MS3D_LAUNCH_CHECK();
     bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
     MS3D_LAUNCH_CHECK();
-    bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size);
+    bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
     MS3D_LAUNCH_CHECK();
     bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
     MS3D_LAUNCH_CHECK();
-    bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
-                                                          w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                          w.scratch_seed, w.cl_size, w.cl_start);
-    MS3D_LAUNCH_CHECK();
+    // Dense symmetric graphs (shifted coordinates: hundreds of neighbours per point, a handful of BFS levels)
+    // are expanded by the whole chip level by level; sparse or capped (directed) graphs by the replay kernel.
+    bool replay = true;
+    if (n_edges >= (long)N * 24) {
+        int h[8];
+        MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipStreamSynchronize(stream));
+        const int nwork = h[0];
+        if (h[5] == 0) {
+            replay = false;
+            if (nwork > 0) {
+                glob_init_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa,
+                                                                            w.comp_base, w.done, w.seg_start, w.seg_cnt,
+                                                                            w.claim);
+                MS3D_LAUNCH_CHECK();
+                const int grid = 256 * 8;
+                int level = 0;
+                for (;;) {
+                    for (int it = 0; it < 16; it++, level++) {
+                        int *Fc = (level & 1) ? w.Fb : w.Fa, *Fn = (level & 1) ? w.Fa : w.Fb;
+                        int *nFc = w.counters + 6 + (level & 1), *nFn = w.counters + 6 + ((level + 1) & 1);
+                        glob_claim_kernel<<<grid, 256, 0, stream>>>(thr, sem, ball_idx, start_len, w.root, Fc, nFc,
+                                                                   w.comp_base, w.done, w.seg_start, w.claim,
+                                                                   w.scratch_node, w.scratch_seed);
+                        MS3D_LAUNCH_CHECK();
+                        glob_update_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.counters, w.done,
+                                                                                      w.seg_start, w.seg_cnt);
+                        MS3D_LAUNCH_CHECK();
+                        glob_win_kernel<false><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim,
+                                                                        w.cnt, nullptr, nullptr, nullptr, nullptr);
+                        MS3D_LAUNCH_CHECK();
+                        int rc2 = ms3d_exclusive_scan_i32(w.cnt, w.cnt, N, nFn, w.scan_ws, stream);
+                        if (rc2) return rc2;
+                        glob_win_kernel<true><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim,
+                                                                       nullptr, w.cnt, Fn, w.seg_start, w.seg_cnt);
+                        MS3D_LAUNCH_CHECK();
+                    }
+                    MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+                    MS3D_CHECK(hipStreamSynchronize(stream));
+                    if (h[6 + (level & 1)] == 0) break;  // frontier empty: every component is exhausted
+                }
+                glob_finish_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.counters, w.comp_size,
+                                                                              w.comp_base, w.cl_size, w.cl_start);
+                MS3D_LAUNCH_CHECK();
+            }
+        }
+    }
+    if (replay) {
+        bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        MS3D_LAUNCH_CHECK();
+    }
     bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
     MS3D_LAUNCH_CHECK();
     int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
@@ -376,22 +560,22 @@ size_t ms3d_bfs_workspace_bytes(int N)
     return carve(w, N > 0 ? N : 1, nullptr);
 }
 
-int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, const int *start_len, int N,
-                        int threshold, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
+int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, long n_edges, const int *start_len,
+                        int N, int threshold, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
                         size_t workspace_bytes, ms3d_stream_t stream)
 {
     Thr thr{0, threshold, 0.f};
-    return bfs_run(thr, semantic_label, ball_query_idxs, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
-                   workspace_bytes, (hipStream_t)stream);
+    return bfs_run(thr, semantic_label, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts,
+                   workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_idxs, const int *start_len, int N,
-                        float threshold, int class_id, int *cluster_idxs, int *cluster_offsets, int *counts,
+int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_idxs, long n_edges,
+                        const int *start_len, int N, float threshold, int class_id, int *cluster_idxs, int *cluster_offsets, int *counts,
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
 {
     const float m = class_numpoint_mean[class_id];  // bfs_cluster.cpp:113-120
     Thr thr{1, 0, (m == -1.f) ? threshold : threshold * m};
-    return bfs_run(thr, nullptr, ball_query_idxs, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+    return bfs_run(thr, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, (hipStream_t)stream);
 }
 

@@ -141,12 +141,13 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
                 if (!any[u]) continue;                                  // wave-uniform: none of the 16 rows has it
-                const float *w = sW + ((size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+                // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
+                const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
 #pragma unroll
                     for (int nb = 0; nb < NBT; nb++)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
                 }
             }
         }
@@ -200,8 +201,17 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     const int waves = blockDim.x >> 6;
     const int nb0 = blockIdx.y * NBT;
     float *sW = lds;
-    float *s_part = lds + (size_t)p.G * p.NCH * 4 * p.NBtot * 64;  // [2*Cout] when bn_x
-    const size_t per_offset = (size_t)p.NCH * 4 * p.NBtot * 64;
+    float *s_part = lds + (size_t)p.G * p.NCH * 4 * NBT * 64;  // [2*Cout] when bn_x
+    const int slab4 = NBT * 16;                                    // float4s per (offset, ch, t) in the LDS image
+    // copy offsets [k_lo, k_lo+cnt) of this block's column slice: contiguous NBT*64 floats per (k, ch, t)
+    auto stage = [&](int k_lo, int cnt) {
+        const int rows = cnt * p.NCH * 4;
+        for (int e = threadIdx.x; e < rows * slab4; e += blockDim.x) {
+            const int r = e / slab4, c4 = e - r * slab4;
+            reinterpret_cast<f32x4 *>(sW)[e] =
+                reinterpret_cast<const f32x4 *>(p.wf + ((size_t)k_lo * p.NCH * 4 + r) * p.NBtot * 64 + (size_t)nb0 * 64)[c4];
+        }
+    };
 
     if (p.bn_x) {
         for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
@@ -214,8 +224,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
 
     if (p.G >= p.K) {
         // all weights resident: persistent waves walk a contiguous range of tiles
-        for (size_t t = threadIdx.x; t < per_offset * p.K / 4; t += blockDim.x)
-            reinterpret_cast<f32x4 *>(sW)[t] = reinterpret_cast<const f32x4 *>(p.wf)[t];
+        stage(0, p.K);
         __syncthreads();
         const int total_waves = nblk * waves;
         const int chunk = (p.ntiles + total_waves - 1) / total_waves;
@@ -241,8 +250,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         for (int g0 = 0; g0 < p.K; g0 += p.G) {
             const int gn = min(p.G, p.K - g0);
             __syncthreads();
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wf + per_offset * g0);
-            for (size_t t = threadIdx.x; t < per_offset * gn / 4; t += blockDim.x) reinterpret_cast<f32x4 *>(sW)[t] = src[t];
+            stage(g0, gn);
             __syncthreads();
             if (tile < p.ntiles) accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, q, nb0, acc);
         }
@@ -581,24 +589,62 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+struct FwdGeom {
+    int nbt, ny, threads, nblk, G;
+    size_t lds;
+    bool ok;
+};
+// Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
+// bottom of the U-Net) are spread over the chip by giving each wave fewer output columns and each block fewer waves.
+FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
+{
+    FwdGeom g{};
+    const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
+    const int ntiles = ms3d_divup(Vout, 16);
+    int ny = ms3d_divup(NBtot, MAX_NBT);
+    while (NBtot % ny != 0) ny++;
+    while ((long)ntiles * ny < 1024 && ny < NBtot) {  // more column splits until ~4 waves per CU exist
+        ny++;
+        while (NBtot % ny != 0) ny++;
+    }
+    g.ny = ny;
+    g.nbt = NBtot / ny;
+    const size_t per_offset = (size_t)NCH * 4 * g.nbt * 64 * sizeof(float);  // LDS bytes per offset (column slice)
+    const size_t extra = with_bn_partial ? 2 * (size_t)Cout * sizeof(float) : 0;
+    const bool resident = per_offset * K + extra <= LDS_BUDGET;
+    if (resident) {
+        g.G = K;
+        const size_t need = per_offset * K + extra;
+        int threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
+        while (threads > 128 && (long)ms3d_divup(ntiles, threads / 64) * ny < 512) threads >>= 1;  // few tiles: more blocks
+        g.threads = threads;
+        g.nblk = ms3d_divup(ntiles, threads / 64);
+        if (g.nblk > 1024) g.nblk = 1024;
+        g.lds = need;
+    } else {
+        g.G = (int)((LDS_BUDGET - extra) / per_offset);
+        if (g.G > K) g.G = K;
+        int waves = ms3d_divup(ntiles, 64);
+        waves = waves < 2 ? 2 : (waves > 16 ? 16 : waves);
+        g.threads = waves * 64;
+        g.nblk = ms3d_divup(ntiles, waves);
+        g.lds = per_offset * g.G + extra;
+    }
+    if (g.nblk < 1) g.nblk = 1;
+    g.ok = g.G >= 1 && g.nbt >= 1 && g.nbt <= MAX_NBT;
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
 {
-    // number of [2][Cout] partial rows a fused-BN backward-data launch writes (gridDim.x * gridDim.y)
-    const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
-    const int ny = ms3d_divup(NBtot, MAX_NBT);
-    const size_t per_offset = (size_t)NCH * 4 * NBtot * 64 * sizeof(float);
-    const bool resident = per_offset * K + 2 * Cout * sizeof(float) <= LDS_BUDGET;
-    const int ntiles = ms3d_divup(Vout, 16);
-    int nblk;
-    if (resident) {
-        const size_t need = per_offset * K + 2 * Cout * sizeof(float);
-        const int threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
-        nblk = ms3d_divup(ntiles, threads / 64);
-        if (nblk > 1024) nblk = 1024;
-    } else
-        nblk = ms3d_divup(ntiles, 16);
-    if (nblk < 1) nblk = 1;
-    return nblk * ny;
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true);
+    return g.nblk * g.ny;
 }
 
 // out = conv(act(in)) [+ residual]; see ConvArgs.  wf from ms3d_spconv_prep_weights.
@@ -614,39 +660,20 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.NCH = ms3d_divup(Cin, 16); p.NBtot = ms3d_divup(Cout, 16); p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
-    const int ny = ms3d_divup(p.NBtot, MAX_NBT);
-    const int nbt = ms3d_divup(p.NBtot, ny);
-    if (p.NBtot % ny != 0) return MS3D_E_UNSUPPORTED;  // column blocks must split evenly (true for 16..224)
-    const size_t per_offset = (size_t)p.NCH * 4 * p.NBtot * 64 * sizeof(float);
-    const size_t extra = bn_x ? 2 * (size_t)Cout * sizeof(float) : 0;
-    const bool resident = per_offset * K + extra <= LDS_BUDGET;
-    int threads, nblk;
-    if (resident) {
-        p.G = K;
-        // keep >= 16 waves per CU whatever the LDS footprint of the weight image is
-        const size_t need = per_offset * K + extra;
-        threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
-        nblk = ms3d_divup(p.ntiles, threads / 64);
-        if (nblk > 1024) nblk = 1024;
-    } else {
-        p.G = (int)((LDS_BUDGET - extra) / per_offset);
-        if (p.G < 1) return MS3D_E_UNSUPPORTED;
-        threads = 1024;
-        nblk = ms3d_divup(p.ntiles, 16);
-    }
-    if (nblk < 1) nblk = 1;
-    const size_t lds = per_offset * p.G + extra;
-    dim3 grid(nblk, ny);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr);
+    if (!g.ok) return MS3D_E_UNSUPPORTED;
+    p.G = g.G;
+    dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
-    switch (nbt) {
-        case 1: return launch_fwd<1>(p, grid, threads, lds, aligned, stream);
-        case 2: return launch_fwd<2>(p, grid, threads, lds, aligned, stream);
-        case 3: return launch_fwd<3>(p, grid, threads, lds, aligned, stream);
-        case 4: return launch_fwd<4>(p, grid, threads, lds, aligned, stream);
-        case 5: return launch_fwd<5>(p, grid, threads, lds, aligned, stream);
-        case 6: return launch_fwd<6>(p, grid, threads, lds, aligned, stream);
-        case 7: return launch_fwd<7>(p, grid, threads, lds, aligned, stream);
-        case 8: return launch_fwd<8>(p, grid, threads, lds, aligned, stream);
+    switch (g.nbt) {
+        case 1: return launch_fwd<1>(p, grid, g.threads, g.lds, aligned, stream);
+        case 2: return launch_fwd<2>(p, grid, g.threads, g.lds, aligned, stream);
+        case 3: return launch_fwd<3>(p, grid, g.threads, g.lds, aligned, stream);
+        case 4: return launch_fwd<4>(p, grid, g.threads, g.lds, aligned, stream);
+        case 5: return launch_fwd<5>(p, grid, g.threads, g.lds, aligned, stream);
+        case 6: return launch_fwd<6>(p, grid, g.threads, g.lds, aligned, stream);
+        case 7: return launch_fwd<7>(p, grid, g.threads, g.lds, aligned, stream);
+        case 8: return launch_fwd<8>(p, grid, g.threads, g.lds, aligned, stream);
     }
     return MS3D_E_UNSUPPORTED;
 }
@@ -679,7 +706,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     if (nb > 14) return MS3D_E_UNSUPPORTED;
     int rc;
     // KG * NBT <= 28 accumulators of 4 VGPRs
-    if (nb == 1) rc = (K >= 27) ? launch_wgrad<27, 1>(p, nblk, stream) : launch_wgrad<8, 1>(p, nblk, stream);
+    if (nb == 1) rc = (K >= 27) ? launch_wgrad<9, 1>(p, nblk, stream) : launch_wgrad<8, 1>(p, nblk, stream);
     else if (nb == 2) rc = (K >= 27) ? launch_wgrad<9, 2>(p, nblk, stream) : launch_wgrad<8, 2>(p, nblk, stream);
     else if (nb == 3) rc = (K >= 27) ? launch_wgrad<9, 3>(p, nblk, stream) : launch_wgrad<8, 3>(p, nblk, stream);
     else if (nb == 4) rc = launch_wgrad<4, 4>(p, nblk, stream);
