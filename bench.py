@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from minsu3d_amd import backend as ms_backend  # noqa: E402
 from minsu3d_amd.config import load_config  # noqa: E402
 from minsu3d_amd.data import synthetic  # noqa: E402
-from minsu3d_amd.model import PointGroup  # noqa: E402
+import minsu3d_amd.model as ms_models  # noqa: E402
 from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -46,12 +46,16 @@ def make_batch(seeds, device, scene_kwargs=None, offset_noise=0.04):
     b["grouping_point_offsets"] = torch.where((b["instance_ids"] >= 0)[:, None],
                                               b["instance_center_xyz"] - b["point_xyz"] + noise,
                                               torch.zeros_like(noise))
+    n = b["point_xyz"].shape[0]
+    sem = torch.full((n, 20), 0.01, device=device)                      # SoftGroup: per-class soft scores
+    sem[torch.arange(n, device=device), b["grouping_semantic_preds"].long()] = 0.8
+    b["grouping_semantic_scores"] = sem
     return b
 
 
 def build(cfg, device, seed=0):
     torch.manual_seed(seed)
-    model = PointGroup(cfg).to(device)
+    model = getattr(ms_models, cfg.model.network.module)(cfg).to(device)
     model.current_epoch = cfg.model.network.prepare_epochs + 1   # grouping + ScoreNet branch on
     model.train()
     return model
@@ -97,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="scenes per GPU per step (reference batch_size 4)")
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches per rank (cycled)")
+    ap.add_argument("--model", default="pointgroup", choices=["pointgroup", "hais", "softgroup"],
+                    help="headline metric = pointgroup; hais / softgroup are the other BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -105,7 +111,7 @@ def main():
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    cfg = load_config(["model=pointgroup", "data=scannetv2"])
+    cfg = load_config([f"model={args.model}", "data=scannetv2"])
     be = ms_backend.get_backend()          # raises if libminsu3d_hip.so is missing: no fallback
 
     model = build(cfg, device)
@@ -145,11 +151,11 @@ def main():
     if rank == 0:
         scenes = world * args.batch * args.steps
         line = {
-            "metric": "scenes/sec (fwd+bwd) PointGroup on ~150k-pt 2cm voxels",
+            "metric": f"scenes/sec (fwd+bwd) {cfg.model.network.module} on ~150k-pt 2cm voxels",
             "value": round(scenes / dt, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PointGroup m=16, synthetic ScanNet-shaped scenes "
+            "config": {"workload": f"{cfg.model.network.module} m={cfg.model.network.m}, synthetic ScanNet-shaped scenes "
                                    f"(~{n_pts / 1000:.0f}k points, ~{n_vox / 1000:.0f}k voxels @2cm each), "
                                    f"{args.batch} scenes/GPU/step, grouping+ScoreNet branch on, fwd+loss+bwd+Adam",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",

@@ -54,6 +54,18 @@ int ms3d_sg_bfs_cluster(const float *class_numpoint_mean /*[host]*/, const int *
                         int *cluster_offsets, int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes,
                         ms3d_stream_t stream);
 
+/* ---- HAIS: replaces hierarchical_aggregation, hierarchical_aggregation/hierarchical_aggregation.h:14-28
+ * (host .cpp:8-184 + .cu:20-204) AND the kept/primary merge of functions/hais_ops.py:55-73: the output is the final
+ * (cluster_idxs, cluster_offsets) pair -- kept fragments first, then primaries with their absorbed fragments
+ * (ascending fragment index).  cluster_idxs capacity [2N,2], cluster_offsets [N+1]; counts -> (nCluster, rows). */
+size_t ms3d_hais_workspace_bytes(int N, int nclass);
+int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *coord_shift, const uint8_t *batch_idxs,
+                                  const int *ball_query_idxs, long n_edges, const int *start_len, int N,
+                                  int using_set_aggr, const float *point_num_avg /*[host]*/,
+                                  const float *radius_avg /*[host]*/, int nclass, int *cluster_idxs,
+                                  int *cluster_offsets, int *counts /*[host,2]*/, void *workspace,
+                                  size_t workspace_bytes, ms3d_stream_t stream);
+
 /* ---- segment ops: replace sec_mean_cuda / sec_min_cuda / sec_max_cuda, sec_mean/sec_mean.h:15-21
  * (kernels sec_mean.cu:12-79).  sec_mean keeps the reference's sequential divide-then-add order
  * per (proposal, channel), so results are bit-identical. */

@@ -117,6 +117,25 @@ class HipBackend:
         return self._bfs("ms3d_sg_bfs_cluster", (mean,), ball_query_idxs, start_len,
                          (C.c_float(threshold), int(class_id)))
 
+    def hierarchical_aggregation(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
+                                 point_num_avg, radius_avg, ignored_label=-1):
+        sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)
+        start_len = self._dev(start_len); batch_idxs = self._dev(batch_idxs)
+        assert sem.dtype == torch.int16 and batch_idxs.dtype == torch.uint8
+        N, dev, ncls = start_len.size(0), start_len.device, len(point_num_avg)
+        pna = (C.c_float * ncls)(*[float(x) for x in point_num_avg])
+        ra = (C.c_float * ncls)(*[float(x) for x in radius_avg])
+        out_idx = torch.empty((max(2 * N, 1), 2), dtype=torch.int32, device=dev)
+        out_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.lib.ms3d_hais_workspace_bytes.restype = C.c_size_t
+        ws = self.ws.get("hais", self.lib.ms3d_hais_workspace_bytes(N, ncls), dev)
+        counts = (C.c_int * 2)(0, 0)
+        _lib.check(self.lib.ms3d_hierarchical_aggregation(
+            _lib.ptr(sem), _lib.ptr(cs), _lib.ptr(batch_idxs), _lib.ptr(ball_idx), C.c_long(ball_idx.numel()),
+            _lib.ptr(start_len), N, int(bool(using_set_aggr)), pna, ra, ncls, _lib.ptr(out_idx), _lib.ptr(out_off),
+            counts, _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_hierarchical_aggregation")
+        return out_idx[:counts[1]], out_off[:counts[0] + 1]
+
     # ------------------------------------------------------------------ segment ops / pools
     def _seg(self, fn_name, inp, offsets):
         inp = self._dev(inp); offsets = self._dev(offsets)

@@ -461,6 +461,14 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     return off;
 }
 
+}  // namespace
+
+// also used by hais.hip (mode 0, threshold 0 = every connected component)
+int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, const int *ball_idx, long n_edges,
+                          const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream);
+
+namespace {
 int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, const int *start_len, int N, int *cluster_idxs,
             int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
@@ -551,6 +559,15 @@ int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, cons
 }
 
 }  // namespace
+
+int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, const int *ball_idx, long n_edges,
+                          const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    Thr thr{mode, thr_i, thr_f};
+    return bfs_run(thr, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+                   workspace_bytes, stream);
+}
 
 extern "C" {
 

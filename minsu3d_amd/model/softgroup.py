@@ -1,0 +1,130 @@
+"""SoftGroup (reference minsu3d/model/softgroup.py:11-183): per-class soft grouping (softmax score > thr ->
+ball query on shifted coordinates -> class-relative BFS threshold), proposals capped at max_proposal_num,
+TinyUnet refinement with classification / mask-scoring / IoU heads and a global average pool per proposal."""
+import torch
+import torch.nn as nn
+
+from ..common_ops.functions import common_ops, softgroup_ops
+from .general_model import GeneralModel, clusters_voxelization
+from .module import TinyUnet
+
+
+class SoftGroup(GeneralModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        m = cfg.model.network.m
+        self.instance_classes = cfg.data.classes - len(cfg.data.ignore_classes)
+        k = self.instance_classes + 1
+        self.tiny_unet = TinyUnet(m)
+        self.classification_branch = nn.Linear(m, k)
+        self.mask_scoring_branch = nn.Sequential(nn.Linear(m, m), nn.ReLU(inplace=True), nn.Linear(m, k))
+        self.iou_score = nn.Linear(m, k)
+        self.voxelization_rand = None
+
+    def _soft_grouping(self, data_dict, sem_scores, offsets):
+        cfg = self.hparams.cfg
+        net = cfg.model.network
+        idx_parts, off_parts, n_prop, n_rows = [], [], 0, 0
+        for class_id in range(cfg.data.classes):
+            if class_id + 1 in cfg.data.ignore_classes:
+                continue
+            object_idxs = (sem_scores[:, class_id] > net.grouping_cfg.score_thr).nonzero().view(-1)
+            if object_idxs.size(0) < net.test_cfg.min_npoint:
+                continue
+            batch_idxs = data_dict["vert_batch_ids"][object_idxs]
+            batch_offsets = torch.cumsum(torch.bincount(batch_idxs + 1), dim=0).int()
+            shifted = (data_dict["point_xyz"][object_idxs] + offsets[object_idxs]).detach().contiguous()
+            idx, start_len = common_ops.ballquery_batch_p(shifted, batch_idxs, batch_offsets, net.grouping_cfg.radius,
+                                                          net.grouping_cfg.mean_active)
+            p_idx, p_off = softgroup_ops.sg_bfs_cluster(cfg.data.point_num_avg, idx, start_len,
+                                                        net.grouping_cfg.npoint_thr, class_id)
+            if p_idx.size(0) == 0:
+                continue
+            p_idx = p_idx.long()
+            p_idx[:, 1] = object_idxs[p_idx[:, 1]]
+            p_idx[:, 0] += n_prop                       # proposals are numbered across classes, in class order
+            idx_parts.append(p_idx)
+            off_parts.append(p_off + n_rows if not off_parts else (p_off + n_rows)[1:])
+            n_prop += p_off.numel() - 1
+            n_rows += p_idx.size(0)
+        if not idx_parts:                                # the reference raises on torch.cat([]) here
+            dev = sem_scores.device
+            return torch.zeros((0, 2), dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        proposals_idx, proposals_offset = torch.cat(idx_parts, 0), torch.cat(off_parts).int()
+        cap = net.train_cfg.max_proposal_num
+        if proposals_offset.numel() > cap:               # reference softgroup.py:80-83 (keeps `cap` proposals)
+            proposals_offset = proposals_offset[:cap + 1]
+            proposals_idx = proposals_idx[:int(proposals_offset[-1])]
+        return proposals_idx, proposals_offset.contiguous()
+
+    def forward(self, data_dict):
+        out = super().forward(data_dict)
+        net = self.hparams.cfg.model.network
+        if self.current_epoch <= net.prepare_epochs:
+            return out
+        sem_scores = data_dict.get("grouping_semantic_scores")
+        if sem_scores is None:
+            sem_scores = out["semantic_scores"].softmax(dim=-1)
+        offsets = data_dict.get("grouping_point_offsets")
+        if offsets is None:
+            offsets = out["point_offsets"]
+        proposals_idx, proposals_offset = self._soft_grouping(data_dict, sem_scores, offsets)
+        out["proposals_idx"], out["proposals_offset"] = proposals_idx, proposals_offset
+        if proposals_offset.numel() <= 1:
+            return out
+        vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"], data_dict["point_xyz"],
+                                         net.instance_voxel_cfg.scale, net.instance_voxel_cfg.spatial_shape, self.device,
+                                         rand=self.voxelization_rand)
+        feats = self.tiny_unet(vox)
+        out["mask_scores"] = self.mask_scoring_branch(feats.features)[p2v]
+        out["instance_batch_idxs"] = feats.coordinates[:, 0][p2v]
+        pooled = self.global_pool(feats)
+        out["cls_scores"] = self.classification_branch(pooled)
+        out["iou_scores"] = self.iou_score(pooled)
+        return out
+
+    def global_pool(self, x):
+        """mean over each proposal's voxels (rows of one proposal are contiguous: quantize keeps first-occurrence order)"""
+        owner = x.coordinates[:, 0]
+        offsets = torch.cumsum(torch.bincount(owner + 1), dim=0).int()
+        return softgroup_ops.global_avg_pool(x.features.contiguous(), offsets)
+
+    def _loss(self, data_dict, output_dict):
+        losses = super()._loss(data_dict, output_dict)
+        if "cls_scores" not in output_dict:
+            return losses
+        net = self.hparams.cfg.model.network
+        K = self.instance_classes
+        pidx = output_dict["proposals_idx"][:, 1].int().contiguous()
+        poff = output_dict["proposals_offset"]
+        ious_cluster = common_ops.get_mask_iou_on_cluster(pidx, poff, data_dict["instance_ids"],
+                                                          data_dict["instance_num_point"])
+        fg = data_dict["instance_semantic_cls"] != -1
+        fg_cls = data_dict["instance_semantic_cls"][fg]
+        fg_ious = ious_cluster[:, fg]
+        n = fg_ious.size(0)
+        # proposal -> ground-truth assignment: positive when the best foreground IoU reaches pos_iou_thr
+        labels = fg_cls.new_full((n,), K).long()
+        if fg_ious.size(1) > 0:
+            best, arg = fg_ious.max(1)
+            pos = best >= net.train_cfg.pos_iou_thr
+            labels[pos] = fg_cls[arg[pos]].long()
+        losses["classification_loss"] = nn.functional.cross_entropy(output_dict["cls_scores"], labels)
+
+        point_label = labels[output_dict["instance_batch_idxs"].long()]
+        rows = torch.arange(point_label.size(0), device=point_label.device)
+        sig = output_dict["mask_scores"].sigmoid()[rows, point_label]
+        mlabel, mmask = common_ops.get_mask_label(pidx, poff, data_dict["instance_ids"],
+                                                  data_dict["instance_semantic_cls"], data_dict["instance_num_point"],
+                                                  ious_cluster, -1, net.train_cfg.pos_iou_thr)
+        mloss = nn.functional.binary_cross_entropy(sig, mlabel.float(), weight=mmask.float(), reduction="sum")
+        losses["mask_scoring_loss"] = mloss / (torch.count_nonzero(mmask) + 1)
+
+        ious_pred = common_ops.get_mask_iou_on_pred(pidx, poff, data_dict["instance_ids"],
+                                                    data_dict["instance_num_point"], sig.detach().contiguous())
+        prop = torch.arange(n, device=labels.device)
+        w = labels < K
+        target = ious_pred[:, fg].max(1)[0] if fg_ious.size(1) > 0 else ious_pred.new_zeros(n)
+        err = nn.functional.mse_loss(output_dict["iou_scores"][prop, labels], target, reduction="none")
+        losses["iou_scoring_loss"] = err[w].sum() / (w.count_nonzero() + 1)
+        return losses

@@ -259,3 +259,60 @@ def test_reference_gpu_kernels_agree(be, oracle):
     assert np.array_equal(sl_r[:, 1], sl_o[:, 1])
     for i in range(n):
         assert np.array_equal(idx_r[sl_r[i, 0]:sl_r[i, 0] + sl_r[i, 1]], idx_o[sl_o[i, 0]:sl_o[i, 0] + sl_o[i, 1]])
+
+
+# ------------------------------------------------------------------ HAIS hierarchical aggregation
+@pytest.mark.parametrize("ci", range(6))
+def test_hais_vs_golden(be, golden_dir, ci):
+    """point aggregation only (using_set_aggr=0): the reference's own CPU output"""
+    g = np.load(os.path.join(golden_dir, f"bfs_case{ci}.npz"))
+    a, o = be.hierarchical_aggregation(dev(g["sem"]), dev(g["xyz"]), dev(g["ball_idx"]), dev(g["start_len"]),
+                                       dev(g["batch_idxs"]), False, g["point_num_avg"].tolist(),
+                                       g["radius_avg"].tolist(), -1)
+    assert np.array_equal(o.cpu().numpy(), g["hais_offsets"])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), g["hais_idxs"].reshape(-1, 2))
+
+
+def _hais_inputs(rng, n=6000):
+    # a few big blobs (primaries) surrounded by small satellites (fragments) of the same class
+    centres = rng.random((5, 3)) * 2
+    big = centres[rng.integers(0, 5, n)] + rng.standard_normal((n, 3)) * 0.03
+    sat_c = centres[rng.integers(0, 5, 40)] + rng.standard_normal((40, 3)) * 0.25
+    sat = sat_c[rng.integers(0, 40, n // 4)] + rng.standard_normal((n // 4, 3)) * 0.008
+    xyz = np.concatenate([big, sat]).astype(np.float32)
+    perm = rng.permutation(len(xyz)); xyz = xyz[perm]
+    b = np.sort(rng.integers(0, 2, len(xyz))).astype(np.uint8)
+    bo = np.concatenate([[0], np.cumsum(np.bincount(b, minlength=2))]).astype(np.int32)
+    sem = np.full(len(xyz), 3, np.int16); sem[rng.random(len(xyz)) < 0.1] = 4
+    return xyz, b, bo, sem
+
+
+@pytest.mark.parametrize("set_aggr", [False, True])
+def test_hais_vs_oracle(be, oracle, set_aggr):
+    rng = np.random.default_rng(21)
+    xyz, b, bo, sem = _hais_inputs(rng)
+    idx, sl = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+    pna = [-1, -1, 100.0, 800.0, 200.0]; ra = [-1, -1, 0.2, 0.35, 0.1]
+    want = oracle.hierarchical_aggregation(sem, xyz, idx, sl, b, set_aggr, pna, ra)
+    a, o = be.hierarchical_aggregation(dev(sem), dev(xyz), dev(idx), dev(sl), dev(b), set_aggr, pna, ra, -1)
+    assert o.numel() - 1 > 3
+    assert np.array_equal(o.cpu().numpy(), want[1])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+def test_hais_set_aggregation_vs_reference_on_gpu(be, oracle):
+    """the reference's own host code + its two GPU kernels (oracle/_ref) with using_set_aggr=1; absorbed fragments
+    arrive in atomic order there, so the absorbed tail of every primary is compared as a multiset"""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libminsu3d_ref.so did not travel to this box")
+    rng = np.random.default_rng(22)
+    xyz, b, bo, sem = _hais_inputs(rng, 4000)
+    idx, sl = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+    pna = np.array([-1, -1, 100.0, 800.0, 200.0], np.float32); ra = np.array([-1, -1, 0.2, 0.35, 0.1], np.float32)
+    ri, ro = oracle.hierarchical_aggregation(sem, xyz, idx, sl, b, True, pna, ra, -1, use_ref=True)
+    a, o = be.hierarchical_aggregation(dev(sem), dev(xyz), dev(idx), dev(sl), dev(b), True, pna.tolist(), ra.tolist(), -1)
+    a = a.cpu().numpy().reshape(-1, 2); o = o.cpu().numpy()
+    assert np.array_equal(o, ro)
+    assert np.array_equal(a[:, 0], ri[:, 0])
+    for c in range(o.size - 1):
+        assert np.array_equal(np.sort(a[o[c]:o[c + 1], 1]), np.sort(ri[o[c]:o[c + 1], 1]))

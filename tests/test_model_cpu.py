@@ -136,3 +136,56 @@ def test_ddp_world_size_2_gloo(tmp_path):
         assert p.exitcode == 0
     assert res[0][1] != res[1][1]                      # ranks own different scenes (no data-path collective)
     assert res[0][3] and res[1][3]                     # gradients identical after the all-reduce
+
+
+def _build(name, seed=0):
+    from minsu3d_amd.config import load_config
+    import minsu3d_amd.model as M
+    torch.manual_seed(seed)
+    cfg = load_config([f"model={name}", "model.network.blocks=[1,2,3]", "model.network.m=16"])
+    model = getattr(M, cfg.model.network.module)(cfg)
+    model.current_epoch = cfg.model.network.prepare_epochs + 1
+    return model
+
+
+def test_hais_step_cpu(cpu_backend):
+    model = _build("hais")
+    # small synthetic boxes are far below ScanNet's class sizes: use matching statistics
+    model.hparams.cfg.data.point_num_avg = [-1, -1] + [400.0] * 18
+    model.hparams.cfg.data.radius_avg = [-1.0, -1.0] + [0.3] * 18
+    batch = small_batch((7, 8))
+    for training in (True, False):              # point aggregation / point + set aggregation
+        model.train(training)
+        out = model(batch)
+        scores, pidx, poff, mask_scores = out["proposal_scores"]
+        assert poff.numel() - 1 >= 1 and mask_scores.shape == (pidx.size(0), 1) and scores.shape[0] == poff.numel() - 1
+    model.train()
+    losses = model._loss(batch, model(batch))
+    assert {"mask_loss", "score_loss"} <= set(losses)
+    sum(losses.values()).backward()
+    assert model.mask_branch[0].weight.grad.abs().sum() > 0 and model.backbone.unet[0].kernel.grad.abs().sum() > 0
+    model.current_epoch = 300                    # mask-filtered score features + IoU on predicted masks
+    losses = model._loss(batch, model(batch))
+    assert all(torch.isfinite(v) for v in losses.values())
+
+
+def test_softgroup_step_cpu(cpu_backend):
+    model = _build("softgroup")
+    model.hparams.cfg.data.point_num_avg = [-1, -1] + [400.0] * 18
+    batch = small_batch((9, 10))
+    n, C = batch["point_xyz"].size(0), model.hparams.cfg.data.classes
+    sem = torch.full((n, C), 0.01)
+    lab = batch["grouping_semantic_preds"].long()
+    sem[torch.arange(n), lab] = 0.8
+    sem[torch.arange(n), (lab + 1) % C] = 0.25   # soft grouping: a point may enter two classes' proposals
+    batch["grouping_semantic_scores"] = sem
+    out = model(batch)
+    P = out["proposals_offset"].numel() - 1
+    assert 1 <= P <= 200 and out["cls_scores"].shape == (P, 19) and out["iou_scores"].shape == (P, 19)
+    assert out["mask_scores"].shape == (out["proposals_idx"].size(0), 19)
+    losses = model._loss(batch, out)
+    assert {"classification_loss", "mask_scoring_loss", "iou_scoring_loss"} <= set(losses)
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    assert model.iou_score.weight.grad is not None and model.tiny_unet.unet[0].blocks.block0.conv_branch[2].kernel.grad.abs().sum() > 0

@@ -71,3 +71,46 @@ def test_step_is_reproducible_on_device():
     o1 = m(b); o2 = m(b)
     assert torch.equal(o1["proposal_scores"][1], o2["proposal_scores"][1])
     assert torch.equal(o1["semantic_scores"], o2["semantic_scores"])
+
+
+@pytest.mark.parametrize("name", ["hais", "softgroup"])
+def test_hais_softgroup_forward_hip_vs_oracle(name):
+    """configs 3/4 callers: identical proposals (bit-exact grouping) and close head outputs / losses"""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from oracle.oracle_backend import OracleBackend
+    from test_model_cpu import _build
+    u = (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3]))
+    ref_model = _build(name, seed=3)
+    ref_model.hparams.cfg.data.point_num_avg = [-1, -1] + [400.0] * 18
+    ref_model.hparams.cfg.data.radius_avg = [-1.0, -1.0] + [0.3] * 18
+    ref_model.voxelization_rand = u
+    hip_model = copy.deepcopy(ref_model).cuda()
+    hip_model.voxelization_rand = tuple(t.cuda() for t in u)
+    batch = small_batch((11, 12))
+    if name == "softgroup":
+        n, C = batch["point_xyz"].size(0), 20
+        sem = torch.full((n, C), 0.01)
+        sem[torch.arange(n), batch["grouping_semantic_preds"].long()] = 0.8
+        batch["grouping_semantic_scores"] = sem
+    prev = backend.set_backend(OracleBackend())
+    try:
+        out_r = ref_model(batch)
+        loss_r = ref_model._loss(batch, out_r)
+    finally:
+        backend.set_backend(prev)
+    backend.set_backend(HipBackend())
+    batch_d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out_h = hip_model(batch_d)
+    loss_h = hip_model._loss(batch_d, out_h)
+    sum(loss_h.values()).backward()
+    if name == "hais":
+        assert torch.equal(out_h["proposal_scores"][1].cpu(), out_r["proposal_scores"][1])
+        assert torch.equal(out_h["proposal_scores"][2].cpu(), out_r["proposal_scores"][2])
+        assert rel(out_h["proposal_scores"][3], out_r["proposal_scores"][3]) < 5e-3
+    else:
+        assert torch.equal(out_h["proposals_idx"].cpu(), out_r["proposals_idx"])
+        assert torch.equal(out_h["proposals_offset"].cpu(), out_r["proposals_offset"])
+        assert rel(out_h["cls_scores"], out_r["cls_scores"]) < 5e-3
+    for k in loss_r:
+        assert abs(float(loss_h[k].detach()) - float(loss_r[k].detach())) < 3e-3 * max(1.0, abs(float(loss_r[k].detach()))), k
