@@ -141,7 +141,15 @@ int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout);
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
-                        const float *bn_mean, const float *bn_invstd, float *bn_partial, ms3d_stream_t stream);
+                        const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
+                        const float *bias /* [Cout] or NULL */, ms3d_stream_t stream);
+/* out_stats != 0 (forward only): bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block
+ * (sum, sum of squares) of the OUTPUT rows (after the residual add) -> feed ms3d_bn_finalize, no extra pass. */
+int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
+                                  ms3d_stream_t stream);
+int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
+                     float *scale, float *shift, ms3d_stream_t stream);
 /* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs
  * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
 int ms3d_spconv_wgrad_row_chunks(int Vout);

@@ -20,52 +20,49 @@ class ConvSpec:
 
 
 class SparseConvFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, W, gamma, beta, spec, bn):
-        be = get_backend()
-        W3 = W.view(spec.K, spec.cin, spec.cout)
-        wf = be.prep_weights(W3, spec.K, spec.cin, spec.cout)
-        pre = (bn["scale"], bn["shift"]) if bn is not None else None
-        y = be.conv_forward(x, wf, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout, pre=pre,
-                            pre_relu=bool(bn and bn["relu"]))
-        ctx.spec, ctx.bn = spec, bn
-        ctx.save_for_backward(x, W)
-        return y
+    """(y, stats) = conv(act(x)) [+ residual];  stats = per-block (sum, sum of squares) of y from the kernel epilogue
+    (non-differentiable side output that lets the next BatchNorm skip its statistics pass)"""
 
     @staticmethod
-    def backward(ctx, dy):
+    def forward(ctx, x, W, gamma, beta, residual, spec, bn, want_stats):
         be = get_backend()
-        spec, bn = ctx.spec, ctx.bn
+        W3 = W.view(spec.K, spec.cin, spec.cout)
+        wf, wft = be.prep_weights_pair(W3, spec.K, spec.cin, spec.cout, mirror_bwd=spec.mirror)
+        pre = (bn["scale"], bn["shift"]) if bn is not None else None
+        res = be.conv_forward(x, wf, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout, pre=pre,
+                              pre_relu=bool(bn and bn["relu"]), residual=residual, out_stats=want_stats)
+        y, stats = res if want_stats else (res, x.new_zeros(0))
+        ctx.spec, ctx.bn, ctx.wft, ctx.has_res = spec, bn, wft, residual is not None
+        ctx.save_for_backward(x, W)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        be = get_backend()
+        spec, bn, wft = ctx.spec, ctx.bn, ctx.wft
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        W3 = W.view(spec.K, spec.cin, spec.cout)
         dx = dgamma = dbeta = None
-        if ctx.needs_input_grad[0]:
-            wft = be.prep_weights(W3, spec.K, spec.cout, spec.cin, transpose=True, mirror=spec.mirror)
+        need_bn = bn is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        if ctx.needs_input_grad[0] or need_bn:
             if bn is None:
                 dx = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
-            elif bn["relu"]:
-                dz, s1s2 = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin,
-                                           bn_bwd=(x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"]))
-                dbeta, dgamma = s1s2[0], s1s2[1]
-                dx = (be.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], s1s2) if bn["training"]
-                      else dz * bn["scale"])
             else:
-                da = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
-                dz, s1s2 = be.bn_bwd_reduce(da, x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"], False)
+                if bn["relu"]:
+                    dz, s1s2 = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin,
+                                               bn_bwd=(x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"]))
+                else:
+                    da = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
+                    dz, s1s2 = be.bn_bwd_reduce(da, x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"], False)
                 dbeta, dgamma = s1s2[0], s1s2[1]
-                dx = (be.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], s1s2) if bn["training"]
-                      else dz * bn["scale"])
+                if ctx.needs_input_grad[0]:
+                    dx = (be.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], s1s2) if bn["training"]
+                          else dz * bn["scale"])
         pre = (bn["scale"], bn["shift"]) if bn is not None else None
         dW = be.conv_backward_weight(x, dy, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout, pre=pre,
                                      pre_relu=bool(bn and bn["relu"])).view_as(W)
-        if bn is not None and dgamma is None:
-            # x itself needs no gradient but gamma / beta still do
-            wft = be.prep_weights(W3, spec.K, spec.cout, spec.cin, transpose=True, mirror=spec.mirror)
-            da = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
-            _, s1s2 = be.bn_bwd_reduce(da, x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"], bn["relu"])
-            dbeta, dgamma = s1s2[0], s1s2[1]
-        return dx, dW, dgamma, dbeta, None, None
+        return dx, dW, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
 
 
 class BNActFn(torch.autograd.Function):
@@ -91,9 +88,45 @@ def bn_act(x, pending):
     return BNActFn.apply(x, pending["gamma"], pending["beta"], pending)
 
 
-def conv(x, W, spec, pending):
+def conv(x, W, spec, pending, residual=None, want_stats=False):
+    """-> (features, stats or None)"""
     if pending is not None and pending.get("gamma") is None:
         x, pending = torch.relu(x), None
     if pending is None:
-        return SparseConvFn.apply(x, W, None, None, spec, None)
-    return SparseConvFn.apply(x, W, pending["gamma"], pending["beta"], spec, pending)
+        y, st = SparseConvFn.apply(x, W, None, None, residual, spec, None, want_stats)
+    else:
+        y, st = SparseConvFn.apply(x, W, pending["gamma"], pending["beta"], residual, spec, pending, want_stats)
+    return y, (st if want_stats else None)
+
+
+class DenseLinearFn(torch.autograd.Function):
+    """y = x @ weight.T + bias for tall-skinny per-point matrices (N ~ 10^5..10^6, 16..32 channels) through the
+    K = 1 path of the conv kernels: one coalesced pass over x instead of a library GEMM tuned for square shapes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        be = get_backend()
+        n, cin, cout = x.size(0), weight.size(1), weight.size(0)
+        W3 = weight.t().contiguous().view(1, cin, cout)
+        wf, wft = be.prep_weights_pair(W3, 1, cin, cout, mirror_bwd=False)
+        ident = be.identity_table(n, x.device)
+        y = be.conv_forward(x.contiguous(), wf, ident, n, 1, cin, cout, bias=bias)
+        ctx.wft, ctx.dims, ctx.has_bias = wft, (n, cin, cout), bias is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = get_backend()
+        (x,) = ctx.saved_tensors
+        n, cin, cout = ctx.dims
+        dy = dy.contiguous()
+        ident = be.identity_table(n, x.device)
+        dx = be.conv_forward(dy, ctx.wft, ident, n, 1, cout, cin) if ctx.needs_input_grad[0] else None
+        dW = be.conv_backward_weight(x, dy, ident, n, 1, cin, cout).view(cin, cout).t()
+        db = dy.sum(0) if ctx.has_bias else None
+        return dx, dW, db
+
+
+def dense_linear(x, weight, bias):
+    return DenseLinearFn.apply(x, weight, bias)

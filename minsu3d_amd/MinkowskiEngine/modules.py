@@ -32,7 +32,9 @@ class _ConvBase(nn.Module):
 class MinkowskiConvolution(_ConvBase):
     """k3 s1 (submanifold, output coords = input coords), k2 s2 (downsample) and k1 s1"""
 
-    def forward(self, x: SparseTensor):
+    def forward(self, x: SparseTensor, residual: SparseTensor = None):
+        """`residual` (same coordinate map as the output) is added in the kernel epilogue -- used by ResidualBlock
+        instead of a separate `+=` pass; not part of ME's API."""
         cm, ts = x.coordinate_manager, x.tensor_stride
         cin, cout = self.in_channels, self.out_channels
         if self.kernel_size == 3 and self.stride == 1:
@@ -51,8 +53,9 @@ class MinkowskiConvolution(_ConvBase):
             out_ts = ts
         else:
             raise NotImplementedError((self.kernel_size, self.stride))
-        y = Fn.conv(x._F, self.kernel, spec, x._pending)
-        return x._like(y, tensor_stride=out_ts)
+        y, stats = Fn.conv(x._F, self.kernel, spec, x._pending,
+                           residual=None if residual is None else residual.features, want_stats=self.training)
+        return x._like(y, tensor_stride=out_ts, stats=stats)
 
 
 class MinkowskiConvolutionTranspose(_ConvBase):
@@ -64,8 +67,8 @@ class MinkowskiConvolutionTranspose(_ConvBase):
         fine = ts // 2
         down, up = cm.k2(fine)  # cached by the encoder's strided convolution
         spec = Fn.ConvSpec(up, down, cm.size(ts), cm.size(fine), 8, self.in_channels, self.out_channels, False)
-        y = Fn.conv(x._F, self.kernel, spec, x._pending)
-        return x._like(y, tensor_stride=fine)
+        y, stats = Fn.conv(x._F, self.kernel, spec, x._pending, want_stats=self.training)
+        return x._like(y, tensor_stride=fine, stats=stats)
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -85,9 +88,15 @@ class MinkowskiBatchNorm(nn.Module):
             with torch.no_grad():
                 rm = bn.running_mean if (self.training and bn.track_running_stats) else None
                 rv = bn.running_var if rm is not None else None
-                mean, invstd, scale, shift = get_backend().bn_stats(
-                    feats.detach(), bn.eps, 0.1 if bn.momentum is None else bn.momentum,
-                    bn.weight.detach() if bn.affine else None, bn.bias.detach() if bn.affine else None, rm, rv)
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                g = bn.weight.detach() if bn.affine else None
+                b = bn.bias.detach() if bn.affine else None
+                if x._stats is not None and x._stats.numel() > 0 and x._pending is None:
+                    # the convolution that produced these rows already summed them in its epilogue
+                    mean, invstd, scale, shift = get_backend().bn_finalize(x._stats, feats.size(0), bn.eps, mom, g, b,
+                                                                           rm, rv)
+                else:
+                    mean, invstd, scale, shift = get_backend().bn_stats(feats.detach(), bn.eps, mom, g, b, rm, rv)
                 if rm is not None:
                     bn.num_batches_tracked += 1
         else:

@@ -52,7 +52,7 @@ class CoordinateManager:
 
 class SparseTensor:
     def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1,
-                 _pending=None):
+                 _pending=None, _stats=None):
         if coordinate_manager is None:
             if device is not None:
                 features, coordinates = features.to(device), coordinates.to(device)
@@ -61,6 +61,7 @@ class SparseTensor:
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride
         self._pending = _pending  # None or dict(scale, shift, relu, bn ctx) not yet applied to _F
+        self._stats = _stats      # per-block (sum, sum^2) partials of _F left by the producing conv's epilogue
 
     # ---- ME attribute surface
     @property
@@ -84,15 +85,17 @@ class SparseTensor:
         if self._pending is not None:
             self._F = Fn.bn_act(self._F, self._pending)
             self._pending = None
+            self._stats = None
 
-    def _like(self, features, pending=None, tensor_stride=None):
+    def _like(self, features, pending=None, tensor_stride=None, stats=None):
         return SparseTensor(features, coordinate_manager=self.coordinate_manager,
                             tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride,
-                            _pending=pending)
+                            _pending=pending, _stats=stats)
 
     def __iadd__(self, other):      # `x += identity` (common.py:48)
         self._materialize()
         self._F = self._F + other.features
+        self._stats = None
         return self
 
     def __add__(self, other):

@@ -314,28 +314,57 @@ class _HipEngine:
                    "ms3d_spconv_prep_weights")
         return wf
 
-    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None):
+    def prep_weights_pair(self, W, K, cin, cout, mirror_bwd=False):
+        """forward image and backward-data image (W^T, offsets mirrored for k3) in one launch"""
+        W = self._dev(W)
+        self.lib.ms3d_spconv_wf_floats.restype = C.c_size_t
+        n1 = self.lib.ms3d_spconv_wf_floats(int(K), int(cin), int(cout))
+        n2 = self.lib.ms3d_spconv_wf_floats(int(K), int(cout), int(cin))
+        buf = torch.empty(n1 + n2, dtype=torch.float32, device=W.device)
+        wf, wft = buf[:n1], buf[n1:]
+        _lib.check(self.lib.ms3d_spconv_prep_weights_pair(_lib.ptr(W), int(K), int(cin), int(cout), int(mirror_bwd),
+                                                          _lib.ptr(wf), _lib.ptr(wft), _lib.stream_handle()),
+                   "ms3d_spconv_prep_weights_pair")
+        return wf, wft
+
+    def identity_table(self, n, device):
+        """[1, n] table for K = 1 (dense per-row matmul through the conv kernel)"""
+        t = self._ident.get((n, device)) if hasattr(self, "_ident") else None
+        if t is None:
+            if not hasattr(self, "_ident"):
+                self._ident = {}
+            if len(self._ident) > 8:
+                self._ident.clear()
+            t = torch.arange(n, dtype=torch.int32, device=device).view(1, n)
+            self._ident[(n, device)] = t
+        return t
+
+    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None,
+                     out_stats=False, bias=None):
         """out = sum_k act(x[nbr[k]]) @ Weff[k] (+ residual).  pre = (scale, shift) fuses BN(+ReLU) on the input.
-        bn_bwd = (bn_x, scale, shift, mean, invstd): backward-data epilogue of a fused BN+ReLU; returns (dz, s1s2)."""
+        bn_bwd = (bn_x, scale, shift, mean, invstd): backward-data epilogue of a fused BN+ReLU; returns (dz, s1s2).
+        out_stats: also return the per-block (sum, sum of squares) partials of the output [nparts, 2, cout]."""
         x = self._dev(x)
         out = torch.empty((vout, cout), dtype=torch.float32, device=x.device)
         ps, pb = (pre if pre is not None else (None, None))
         partial = None
         bnargs = [None] * 5
-        if bn_bwd is not None:
+        if bn_bwd is not None or out_stats:
             nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout))
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
+        if bn_bwd is not None:
             bnargs = [_f32(t) for t in bn_bwd]
         timer = self.kernel_timer
         tok = timer.begin("spconv_fwd", K, cin, cout, nbr) if timer is not None else None
         _lib.check(self.lib.ms3d_spconv_forward(
             _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
             _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
-            *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), _lib.stream_handle()), "ms3d_spconv_forward")
+            *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), int(bool(out_stats)), _lib.ptr(_f32(bias)),
+            _lib.stream_handle()), "ms3d_spconv_forward")
         if tok is not None:
             timer.end(tok)
         if bn_bwd is None:
-            return out
+            return (out, partial) if out_stats else out
         s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)
         _lib.check(self.lib.ms3d_reduce_partials(_lib.ptr(partial), partial.size(0), 2 * cout, _lib.ptr(s1s2),
                                                  _lib.stream_handle()), "ms3d_reduce_partials")
@@ -369,6 +398,17 @@ class _HipEngine:
                                           _lib.ptr(running_var), _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
                                           _lib.ptr(outs[3]), _lib.ptr(ws), self.PARTIAL_ROWS, _lib.stream_handle()),
                    "ms3d_bn_stats")
+        return outs[0], outs[1], outs[2], outs[3]
+
+    def bn_finalize(self, partial, V, eps, momentum, gamma, beta, running_mean, running_var):
+        """statistics from the (sum, sum of squares) partials a conv epilogue left behind -> (mean, invstd, scale, shift)"""
+        C_ = partial.size(2)
+        outs = torch.empty((4, C_), dtype=torch.float32, device=partial.device)
+        _lib.check(self.lib.ms3d_bn_finalize(_lib.ptr(partial), int(partial.size(0)), C.c_long(V), int(C_),
+                                             C.c_float(eps), C.c_float(momentum), _lib.ptr(_f32(gamma)),
+                                             _lib.ptr(_f32(beta)), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                             _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), _lib.ptr(outs[3]),
+                                             _lib.stream_handle()), "ms3d_bn_finalize")
         return outs[0], outs[1], outs[2], outs[3]
 
     def bn_apply(self, x, scale, shift, relu):

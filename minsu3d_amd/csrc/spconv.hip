@@ -39,13 +39,16 @@ struct ConvArgs {
     const float *pre_scale;  // [Cin] or null : a = max(0, x*scale + shift)
     const float *pre_shift;
     const float *residual;   // [Vout, Cout] or null, added in the epilogue
+    const float *bias;       // [Cout] or null, added in the epilogue (dense per-point Linear layers: K = 1)
     // backward-data epilogue of a fused BN+ReLU (all null when unused)
     const float *bn_x;       // [Vout, Cout] input of the fused BN (forward)
     const float *bn_scale;   // [Cout]
     const float *bn_shift;   // [Cout]
     const float *bn_mean;    // [Cout]
     const float *bn_invstd;  // [Cout]
-    float *bn_partial;       // [gridDim.x][2][Cout] : sum(dz), sum(dz * xhat)
+    float *bn_partial;       // [gridDim.x*gridDim.y][2][Cout] : sum(dz), sum(dz * xhat)   (bn_x != null)
+                             //                               or sum(out), sum(out^2)       (out_stats != 0)
+    int out_stats;           // forward: per-channel batch statistics of the OUTPUT ride in the epilogue
     int Vout, K, Cin, Cout;
     int NCH;    // ceil(Cin / 16)
     int NBtot;  // Cout / 16
@@ -57,9 +60,25 @@ struct ConvArgs {
 // ------------------------------------------------------------------ weight permutation
 // Wf[((k*NCH + ch)*4 + t)*NBtot + nb][lane] = Weff[k][c = 16ch + 4q + t][j = 16nb + (lane & 15)],  q = lane >> 4
 __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restrict__ wf, int K, int Cin_e, int Cout_e,
-                                    int NCH, int NBtot, int transpose, int mirror)
+                                    int NCH, int NBtot, int transpose, int mirror, float *__restrict__ wf2, int NCH2,
+                                    int NBtot2, int mirror2)
 {
     const long total = (long)K * NCH * 4 * NBtot * 64;
+    if (wf2) {
+        // second image in the same launch: the backward-data operator (transposed, Cin/Cout swapped)
+        const long total2 = (long)K * NCH2 * 4 * NBtot2 * 64;
+        for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total2; o += (long)gridDim.x * blockDim.x) {
+            const int lane = (int)(o & 63);
+            long r = o >> 6;
+            const int nb = (int)(r % NBtot2); r /= NBtot2;
+            const int t = (int)(r & 3); r >>= 2;
+            const int ch = (int)(r % NCH2);
+            const int k = (int)(r / NCH2);
+            const int c = 16 * ch + 4 * (lane >> 4) + t, j = 16 * nb + (lane & 15);  // c < Cout_e, j < Cin_e
+            const int ks = mirror2 ? (K - 1 - k) : k;
+            wf2[o] = (c < Cout_e && j < Cin_e) ? W[((size_t)ks * Cin_e + j) * Cout_e + c] : 0.f;
+        }
+    }
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(o & 63);
         long r = o >> 6;
@@ -170,6 +189,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
                 float v = acc[nb][r];
                 const size_t o = (size_t)row * p.Cout + j;
                 if (p.residual) v += p.residual[o];
+                if (p.bias) v += p.bias[j];
                 if (p.bn_x) {
                     // backward of the fused BN+ReLU that fed the forward conv: dz = da * [x*scale+shift > 0]
                     const float x = p.bn_x[o];
@@ -177,11 +197,14 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
                     v = (z > 0.f) ? v : 0.f;
                     s1 += v;
                     s2 += v * ((x - p.bn_mean[j]) * p.bn_invstd[j]);
+                } else if (p.out_stats) {
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
                 }
                 p.out[o] = v;
             }
         }
-        if (p.bn_x) {
+        if (p.bn_x || p.out_stats) {
             // reduce over the 4 q-groups (same column), then one LDS atomic per column per wave
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -213,7 +236,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         }
     };
 
-    if (p.bn_x) {
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) {
         for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
     }
     // XCD-aware placement: blocks b, b+8, b+16.. share an XCD (dispatch is round-robin), give them adjacent tiles
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         }
         if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
-    if (p.bn_x) {
+    if (with_partial) {
         __syncthreads();
         float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
         // each blockIdx.y owns its own columns; others stay zero and are summed away by the finalize kernel
@@ -584,10 +608,29 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
     const int NCH = ms3d_divup(Cin_eff, 16), NBtot = ms3d_divup(Cout_eff, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64;
     prep_weights_kernel<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
-        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror);
+        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror, nullptr, 0, 0, 0);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
+
+// forward image wf (W[K][Cin][Cout]) and backward-data image wft (W^T, optionally offset-mirrored) in ONE launch
+int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
+                                  ms3d_stream_t stream)
+{
+    const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
+    const int NCH2 = ms3d_divup(Cout, 16), NBtot2 = ms3d_divup(Cin, 16);
+    const long total = (long)K * NCH * 4 * NBtot * 64, total2 = (long)K * NCH2 * 4 * NBtot2 * 64;
+    const long m = total > total2 ? total : total2;
+    prep_weights_kernel<<<(int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
+        W, wf, K, Cin, Cout, NCH, NBtot, 0, 0, wft, NCH2, NBtot2, mirror_bwd);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// mean / invstd / scale / shift (+ running stats) from per-block (sum, sum of squares) partials written by a conv epilogue
+int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
+                     float *scale, float *shift, ms3d_stream_t stream);
 
 }  // extern "C"
 
@@ -651,16 +694,19 @@ int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
-                        const float *bn_mean, const float *bn_invstd, float *bn_partial, ms3d_stream_t stream_)
+                        const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
+                        const float *bias, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
     ConvArgs p;
+    p.bias = bias;
+    p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.NCH = ms3d_divup(Cin, 16); p.NBtot = ms3d_divup(Cout, 16); p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr || p.out_stats);
     if (!g.ok) return MS3D_E_UNSUPPORTED;
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
@@ -739,6 +785,18 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
     MS3D_LAUNCH_CHECK();
     bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 256, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
                                                                   running_mean, running_var, mean, invstd, scale, shift);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
+                     float *scale, float *shift, ms3d_stream_t stream)
+{
+    if (V <= 0) return MS3D_E_UNSUPPORTED;
+    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 256, 0, (hipStream_t)stream>>>(partial, nparts, C, V, eps, momentum, gamma,
+                                                                                beta, running_mean, running_var, mean,
+                                                                                invstd, scale, shift);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

@@ -2,11 +2,22 @@
 import torch.nn as nn
 
 from ... import MinkowskiEngine as ME
+from ...MinkowskiEngine import functional as ME_F
 from .common import ResidualBlock, UBlock
 
 
+class PointLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose forward runs the tall-skinny [N_points, 16..32] matmul
+    through the engine's K = 1 MFMA path instead of a library GEMM"""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.size(0) >= 4096:
+            return ME_F.dense_linear(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _head(c_in, c_out):
-    return nn.Sequential(nn.Linear(c_in, c_in), nn.BatchNorm1d(c_in), nn.ReLU(inplace=True), nn.Linear(c_in, c_out))
+    return nn.Sequential(PointLinear(c_in, c_in), nn.BatchNorm1d(c_in), nn.ReLU(inplace=True), PointLinear(c_in, c_out))
 
 
 class Backbone(nn.Module):

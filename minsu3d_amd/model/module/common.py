@@ -30,9 +30,12 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        y = self.conv_branch(x)
-        y += skip
-        return y
+        h = x
+        for layer in self.conv_branch[:-1]:
+            h = layer(h)
+        # `y = conv(h); y += skip` of the reference (common.py:43-49) as one kernel: the residual add and the batch
+        # statistics the next BatchNorm needs ride in the last convolution's epilogue
+        return self.conv_branch[-1](h, residual=skip)
 
 
 class UBlock(nn.Module):

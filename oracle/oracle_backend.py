@@ -94,12 +94,23 @@ class OracleBackend:
         a = x * pre[0] + pre[1]
         return torch.relu(a) if pre_relu else a
 
-    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None):
+    def prep_weights_pair(self, W, K, cin, cout, mirror_bwd=False):
+        return (self.prep_weights(W, K, cin, cout), self.prep_weights(W, K, cout, cin, transpose=True, mirror=mirror_bwd))
+
+    def identity_table(self, n, device):
+        return torch.arange(n, dtype=torch.int32).view(1, n)
+
+    def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None,
+                     out_stats=False, bias=None):
         a = self._act(x.detach(), pre, pre_relu)
         out = _t(O.conv_fwd(_np(a), wf, _np(nbr).T))
         if residual is not None:
-            out = out + residual
+            out = out + residual.detach()
+        if bias is not None:
+            out = out + bias.detach()
         if bn_bwd is None:
+            if out_stats:
+                return out, torch.stack([out.sum(0), (out * out).sum(0)])[None]
             return out
         bx, scale, shift, mean, invstd = bn_bwd
         dz = out * ((bx * scale + shift) > 0)
@@ -126,6 +137,20 @@ class OracleBackend:
             unbiased = var * V / max(V - 1, 1)
             running_mean.mul_(1 - momentum).add_(momentum * mean.float())
             running_var.mul_(1 - momentum).add_(momentum * unbiased.float())
+        return mean.float(), invstd, scale, shift
+
+    def bn_finalize(self, partial, V, eps, momentum, gamma, beta, running_mean, running_var):
+        s = partial.double().sum(0)
+        mean = s[0] / V
+        var = (s[1] / V - mean * mean).clamp_min(0)
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        g = gamma if gamma is not None else torch.ones_like(invstd)
+        b = beta if beta is not None else torch.zeros_like(invstd)
+        scale = g * invstd
+        shift = b - mean.float() * scale
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * (var * V / max(V - 1, 1)).float())
         return mean.float(), invstd, scale, shift
 
     def bn_apply(self, x, scale, shift, relu):

@@ -96,6 +96,18 @@ def test_conv_kernels_vs_oracle(be, oracle, cin, cout, K):
     got2 = be.conv_forward(xd, be.prep_weights(Wd, K, cin, cout), nbr_d, vout, K, cin, cout,
                            pre=(dev(scale), dev(shift)), pre_relu=True, residual=dev(res))
     assert rel_err(got2.cpu(), torch.from_numpy(want2)) < RTOL
+    # output statistics from the epilogue (feeds the next BatchNorm without another pass) + bias
+    bias = rng.standard_normal(cout).astype(np.float32)
+    got3, partial = be.conv_forward(xd, be.prep_weights(Wd, K, cin, cout), nbr_d, vout, K, cin, cout, residual=dev(res),
+                                    out_stats=True, bias=dev(bias))
+    want3 = (want + res + bias).astype(np.float64)
+    assert rel_err(got3.cpu(), torch.from_numpy(want3)) < RTOL
+    st = partial.double().sum(0).cpu().numpy()
+    assert np.allclose(st[0], want3.sum(0), rtol=1e-4, atol=1e-3 * np.abs(want3).sum(0).max())
+    assert np.allclose(st[1], (want3 * want3).sum(0), rtol=1e-4)
+    wf_p, wft_p = be.prep_weights_pair(Wd, K, cin, cout, mirror_bwd=(K == 27))
+    assert torch.equal(wf_p, be.prep_weights(Wd, K, cin, cout))
+    assert torch.equal(wft_p, be.prep_weights(Wd, K, cout, cin, transpose=True, mirror=(K == 27)))
     # backward-data
     g = rng.standard_normal((vout, cout)).astype(np.float32)
     want_dx = oracle.conv_bwd_data(g, W, nbr, vin)
