@@ -129,6 +129,10 @@ int ms3d_downsample(const int *coords, int V, int tensor_stride, int *out_coords
 int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_down, int *nbr_up,
                  ms3d_stream_t stream);
 
+/* spatial sort keys (batch | 45-bit Morton code): rows sorted by this key keep a voxel's 26 neighbours close in
+ * memory, so the conv gathers of one XCD stay inside its own L2 slice */
+int ms3d_morton_keys(const int *coords, int V, long long *keys, ms3d_stream_t stream);
+
 /* weights W[K][Cin][Cout] -> MFMA-fragment order.  transpose=1 (+mirror=1 for k3) gives the backward-data
  * operator: Weff[k] = W[mirror ? K-1-k : k]^T with Cin_eff = Cout, Cout_eff = Cin. */
 size_t ms3d_spconv_wf_floats(int K, int Cin_eff, int Cout_eff);

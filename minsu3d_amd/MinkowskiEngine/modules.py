@@ -54,7 +54,7 @@ class MinkowskiConvolution(_ConvBase):
         else:
             raise NotImplementedError((self.kernel_size, self.stride))
         y, stats = Fn.conv(x._F, self.kernel, spec, x._pending,
-                           residual=None if residual is None else residual.features, want_stats=self.training)
+                           residual=None if residual is None else residual._raw(), want_stats=self.training)
         return x._like(y, tensor_stride=out_ts, stats=stats)
 
 
@@ -82,7 +82,7 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x: SparseTensor):
         bn = self.bn
-        feats = x.features  # materialise anything pending in front of this BN
+        feats = x._raw()  # materialise anything pending in front of this BN (engine row order)
         use_batch = self.training or not bn.track_running_stats
         if use_batch:
             with torch.no_grad():
@@ -121,4 +121,4 @@ class MinkowskiReLU(nn.Module):
             p = dict(x._pending)
             p["relu"] = True
             return x._like(x._F, pending=p)
-        return x._like(torch.relu(x.features))
+        return x._like(torch.relu(x._raw()))

@@ -18,8 +18,20 @@ class CoordinateManager:
     """coordinates per tensor stride and kernel maps per (stride, kind), built once and shared by every
     convolution of a level and by the backward pass (ME's coordinate manager does the same caching)."""
 
-    def __init__(self, coordinates):
+    def __init__(self, coordinates, spatial_sort=False):
         assert coordinates.dtype == torch.int32 and coordinates.size(1) == 4
+        # Engine-internal row order: voxels sorted by (batch, Morton code) so that the rows a convolution gathers
+        # for neighbouring outputs are neighbours in HBM / the same XCD's L2.  `perm` maps internal row -> caller
+        # row, `inv` the other way; callers never see the internal order (SparseTensor.features un-permutes).
+        self.perm = self.inv = None
+        if spatial_sort:
+            perm = get_backend().spatial_order(coordinates.contiguous())
+            if perm is not None:
+                self.perm = perm
+                self.inv = torch.empty_like(perm)
+                self.inv[perm] = torch.arange(perm.numel(), device=perm.device)
+                self.coords_external = coordinates
+                coordinates = coordinates[perm]
         self.coords = {1: coordinates.contiguous()}
         self._k3 = {}
         self._k2 = {}       # fine stride -> (nbr_down [8,Vc], nbr_up [8,Vf])
@@ -56,8 +68,11 @@ class SparseTensor:
         if coordinate_manager is None:
             if device is not None:
                 features, coordinates = features.to(device), coordinates.to(device)
-            coordinate_manager = CoordinateManager(coordinates.to(torch.int32))
+            coordinate_manager = CoordinateManager(coordinates.to(torch.int32), spatial_sort=True)
+            if coordinate_manager.perm is not None:
+                features = features[coordinate_manager.perm]
         self._F = features
+        self._F_ext = None
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride
         self._pending = _pending  # None or dict(scale, shift, relu, bn ctx) not yet applied to _F
@@ -66,14 +81,28 @@ class SparseTensor:
     # ---- ME attribute surface
     @property
     def features(self):
+        """rows in the CALLER's order (the order of the coordinates the tensor was built from)"""
         self._materialize()
-        return self._F
+        inv = self.coordinate_manager.inv if self.tensor_stride == 1 else None
+        if inv is None:
+            return self._F
+        if self._F_ext is None:
+            self._F_ext = self._F[inv]
+        return self._F_ext
 
     F = features
 
+    def _raw(self):
+        """materialised rows in the engine's internal order"""
+        self._materialize()
+        return self._F
+
     @property
     def coordinates(self):
-        return self.coordinate_manager.coords[self.tensor_stride]
+        cm = self.coordinate_manager
+        if self.tensor_stride == 1 and cm.inv is not None:
+            return cm.coords_external
+        return cm.coords[self.tensor_stride]
 
     C = coordinates
 
@@ -86,6 +115,7 @@ class SparseTensor:
             self._F = Fn.bn_act(self._F, self._pending)
             self._pending = None
             self._stats = None
+            self._F_ext = None
 
     def _like(self, features, pending=None, tensor_stride=None, stats=None):
         return SparseTensor(features, coordinate_manager=self.coordinate_manager,
@@ -93,15 +123,15 @@ class SparseTensor:
                             _pending=pending, _stats=stats)
 
     def __iadd__(self, other):      # `x += identity` (common.py:48)
-        self._materialize()
-        self._F = self._F + other.features
+        self._F = self._raw() + other._raw()
         self._stats = None
+        self._F_ext = None
         return self
 
     def __add__(self, other):
-        return self._like(self.features + other.features)
+        return self._like(self._raw() + other._raw())
 
 
 def cat(*tensors):
     """ME.cat: channel concat of tensors sharing one coordinate map (common.py:93)"""
-    return tensors[0]._like(torch.cat([t.features for t in tensors], dim=1))
+    return tensors[0]._like(torch.cat([t._raw() for t in tensors], dim=1))

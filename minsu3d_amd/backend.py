@@ -273,6 +273,16 @@ class _HipEngine:
                    "ms3d_sparse_quantize")
         return uniq[:nu.value], inv[:n]
 
+    def spatial_order(self, coords):
+        """row permutation that sorts voxels by (batch, Morton code); None = keep the given order"""
+        coords = self._dev(coords)
+        V = coords.size(0)
+        if V < 4096:
+            return None
+        keys = torch.empty(V, dtype=torch.int64, device=coords.device)
+        _lib.check(self.lib.ms3d_morton_keys(_lib.ptr(coords), V, _lib.ptr(keys), _lib.stream_handle()), "ms3d_morton_keys")
+        return torch.sort(keys).indices   # radix sort (rocPRIM through torch): plumbing, not a hot kernel
+
     def kmap_k3(self, coords, ts):
         coords = self._dev(coords)
         V, dev = coords.size(0), coords.device

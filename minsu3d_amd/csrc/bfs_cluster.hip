@@ -84,7 +84,9 @@ __global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited
     if (i < 8) counters[i] = 0;
 }
 
-// one wave per point, lanes stride its neighbour list
+// one wave per point, lanes stride its neighbour list.  The root of i is resolved once per wave; an edge whose
+// neighbour already points at that root is dismissed with one cached load (a stale parent[j] == root(i) is still
+// proof of membership: sets only ever merge), so the atomic find/union chain runs for the few merging edges only.
 __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
                                                        const int *__restrict__ ball_idx,
                                                        const int *__restrict__ start_len, int *parent)
@@ -92,12 +94,20 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int
     const int waves = blockDim.x >> 6;
     for (int i = blockIdx.x * waves + wave_id(); i < N; i += gridDim.x * waves) {
         const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+        if (ln <= 1) continue;  // only itself
         const int lab = thr.mode == 0 ? (int)sem[i] : 0;
-        for (int t = lane_id(); t < ln; t += 64) {
-            const int j = ball_idx[st + t];
-            if (j == i) continue;
-            if (thr.mode == 0 && (int)sem[j] != lab) continue;  // bfs_cluster.cpp:44
-            uf_union(parent, i, j);
+        int ri = uf_find(parent, i);
+        for (int t0 = 0; t0 < ln; t0 += 64) {
+            const int t = t0 + lane_id();
+            bool merge = false;
+            int j = i;
+            if (t < ln) {
+                j = ball_idx[st + t];
+                if (j != i && (thr.mode != 0 || (int)sem[j] == lab)) merge = parent[j] != ri;  // bfs_cluster.cpp:44
+            }
+            if (__ballot(merge) == 0ull) continue;
+            if (merge) uf_union(parent, i, j);
+            ri = uf_find(parent, i);  // refreshed for the next 64 edges
         }
     }
 }

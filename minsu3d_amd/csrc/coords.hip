@@ -144,6 +144,27 @@ __global__ void kmap_k2_kernel(const int *__restrict__ parent, const int *__rest
     nbr_up[(size_t)k * Vf + f] = p;
 }
 
+// 64-bit spatial sort key: batch index, then the 45-bit Morton code of the biased (x,y,z)
+__device__ __forceinline__ unsigned long long spread3(unsigned v)
+{
+    unsigned long long x = v & 0x7FFFull;  // 15 bits -> every third bit
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void morton_keys_kernel(const int *__restrict__ coords, int V, long long *__restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const unsigned long long m = spread3((unsigned)(c.y + 16384)) | (spread3((unsigned)(c.z + 16384)) << 1) |
+                                 (spread3((unsigned)(c.w + 16384)) << 2);
+    keys[i] = (long long)(((unsigned long long)(unsigned)(c.x & 0x3FFFF) << 45) | m);
+}
+
 struct CoordWs {
     unsigned long long *keys;
     int *vals, *slot_of_row, *flag, *rank, *total;
@@ -253,6 +274,14 @@ int ms3d_downsample(const int *coords, int V, int tensor_stride, int *out_coords
     if (rc) return rc;
     downsample_emit_kernel<<<ms3d_divup(V, 256), 256, 0, stream>>>(V, tensor_stride, coords, w.slot_of_row, w.vals, w.rank,
                                                                  out_coords, parent, koff);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_morton_keys(const int *coords, int V, long long *keys, ms3d_stream_t stream)
+{
+    if (V <= 0) return 0;
+    morton_keys_kernel<<<ms3d_divup(V, 256), 256, 0, (hipStream_t)stream>>>(coords, V, keys);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

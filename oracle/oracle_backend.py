@@ -67,6 +67,9 @@ class OracleBackend:
         u, inv = O.sparse_quantize(_np(coords))
         return _t(u), _t(inv)
 
+    def spatial_order(self, coords):
+        return None   # the CPU checker keeps the caller's row order
+
     def kmap_k3(self, coords, ts):
         return _t(O.kmap_k3(_np(coords), ts).T)
 
