@@ -160,6 +160,19 @@ int ms3d_spconv_wgrad_row_chunks(int Vout);
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
                                 int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                 float *partial_ws, ms3d_stream_t stream);
+/* One-call layer entry points (forward / backward of a fused [BN -> ReLU ->] conv): same kernels as above, enqueued
+ * from native code.  wf_buf holds both weight images (ms3d_spconv_wf_floats(K,Cin,Cout)+(K,Cout,Cin) floats) and is
+ * kept by the caller between forward and backward; ws: ms3d_spconv_layer_ws_floats() floats of scratch. */
+size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout);
+int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
+                              int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
+                              const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
+                              ms3d_stream_t stream);
+int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
+                               const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
+                               const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
+                               int need_dx, float *dx, float *dgb, float *dW, float *ws, ms3d_stream_t stream);
+
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */
 int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *scale, float *shift,

@@ -26,43 +26,39 @@ class SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, gamma, beta, residual, spec, bn, want_stats):
         be = get_backend()
-        W3 = W.view(spec.K, spec.cin, spec.cout)
-        wf, wft = be.prep_weights_pair(W3, spec.K, spec.cin, spec.cout, mirror_bwd=spec.mirror)
         pre = (bn["scale"], bn["shift"]) if bn is not None else None
-        res = be.conv_forward(x, wf, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout, pre=pre,
-                              pre_relu=bool(bn and bn["relu"]), residual=residual, out_stats=want_stats)
-        y, stats = res if want_stats else (res, x.new_zeros(0))
-        ctx.spec, ctx.bn, ctx.wft, ctx.has_res = spec, bn, wft, residual is not None
+        y, stats, wf_buf = be.conv_layer_forward(x, W.view(spec.K, spec.cin, spec.cout), spec.nbr_fwd, spec.vout, spec.K,
+                                                 spec.cin, spec.cout, spec.mirror, pre, bool(bn and bn["relu"]), residual,
+                                                 None, want_stats)
+        if stats is None:
+            stats = x.new_zeros(0)
+        ctx.spec, ctx.bn, ctx.wf_buf, ctx.has_res = spec, bn, wf_buf, residual is not None
         ctx.save_for_backward(x, W)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
         be = get_backend()
-        spec, bn, wft = ctx.spec, ctx.bn, ctx.wft
+        spec, bn = ctx.spec, ctx.bn
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dgamma = dbeta = None
-        need_bn = bn is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
-        if ctx.needs_input_grad[0] or need_bn:
-            if bn is None:
-                dx = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
-            else:
-                if bn["relu"]:
-                    dz, s1s2 = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin,
-                                               bn_bwd=(x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"]))
-                else:
-                    da = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
-                    dz, s1s2 = be.bn_bwd_reduce(da, x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"], False)
-                dbeta, dgamma = s1s2[0], s1s2[1]
-                if ctx.needs_input_grad[0]:
-                    dx = (be.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], s1s2) if bn["training"]
-                          else dz * bn["scale"])
-        pre = (bn["scale"], bn["shift"]) if bn is not None else None
-        dW = be.conv_backward_weight(x, dy, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout, pre=pre,
-                                     pre_relu=bool(bn and bn["relu"])).view_as(W)
-        return dx, dW, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
+        if bn is not None and not bn["relu"]:
+            # BatchNorm without ReLU in front of a convolution (not used by the reference): unfused path
+            wft = be.prep_weights(W.view(spec.K, spec.cin, spec.cout), spec.K, spec.cout, spec.cin, transpose=True,
+                                  mirror=spec.mirror)
+            da = be.conv_forward(dy, wft, spec.nbr_bwd, spec.vin, spec.K, spec.cout, spec.cin)
+            dz, dgb = be.bn_bwd_reduce(da, x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"], False)
+            dx = (be.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], dgb) if bn["training"] else dz * bn["scale"])
+            dW = be.conv_backward_weight(x, dy, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout,
+                                         pre=(bn["scale"], bn["shift"]), pre_relu=False)
+        else:
+            dx, dgb, dW = be.conv_layer_backward(x, dy, ctx.wf_buf, spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout,
+                                                 spec.K, spec.cin, spec.cout, bn, ctx.needs_input_grad[0])
+        dgamma = dgb[1] if dgb is not None else None
+        dbeta = dgb[0] if dgb is not None else None
+        return dx, dW.view_as(W), dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
 
 
 class BNActFn(torch.autograd.Function):

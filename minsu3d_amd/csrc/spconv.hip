@@ -529,7 +529,7 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, long n, int C, cons
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        float v = fmaf(x[e], scale[c], shift[c]);
+        float v = fmaf(x[e], scale[c], shift ? shift[c] : 0.f);
         y[e] = relu ? fmaxf(v, 0.f) : v;
     }
 }
@@ -845,6 +845,76 @@ int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const fl
     MS3D_LAUNCH_CHECK();
     *nparts_out = nblk;
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// One-call layer entry points: everything a fused [BatchNorm -> ReLU ->] convolution needs per direction is
+// enqueued from native code (one host->library transition per layer instead of five).
+// ---------------------------------------------------------------------------------------------------------
+size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
+{
+    // weight images (both orientations) + epilogue partials (fwd: Cout wide, bwd: Cin wide) + wgrad slabs + s1s2
+    const size_t wf = ms3d_spconv_wf_floats(K, Cin, Cout) + ms3d_spconv_wf_floats(K, Cout, Cin);
+    const size_t pf = (size_t)ms3d_spconv_partial_blocks(Vout, K, Cin, Cout) * 2 * Cout;
+    const size_t pb = (size_t)ms3d_spconv_partial_blocks(Vin, K, Cout, Cin) * 2 * Cin;
+    const size_t wg = (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout;
+    return wf + (pf > pb ? pf : pb) + wg + 2 * (size_t)Cin + 64;
+}
+
+// forward: weight images (kept in wf_buf for the backward pass) + conv (+ fused input BN/ReLU, residual, bias) +
+// optional output statistics (stat_partial [ms3d_spconv_partial_blocks(Vout,K,Cin,Cout)][2][Cout])
+int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
+                              int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
+                              const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
+                              ms3d_stream_t stream)
+{
+    float *wf = wf_buf, *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
+    int rc = ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream);
+    if (rc) return rc;
+    return ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, stream);
+}
+
+// backward of the fused layer.  need_dx / bn (scale != NULL) select the pieces:
+//   dz   = conv^T(dy) [* ReLU mask of the fused BN]           -> written to dx (in place: dx doubles as dz)
+//   s1s2 = (sum dz, sum dz*xhat)  = (dbeta, dgamma)            -> dgb [2][Cin]
+//   dx   = scale * (dz - s1/V - xhat*s2/V)  (training)  or  scale * dz  (eval)
+//   dW   = sum_i act(x[nbr])^T dy  through per-chunk slabs in `ws`
+int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
+                               const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
+                               const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
+                               int need_dx, float *dx, float *dgb, float *dW, float *ws, ms3d_stream_t stream)
+{
+    const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
+    const bool bn = scale != nullptr;
+    int rc;
+    if (need_dx || bn) {
+        if (!bn) {
+            rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
+            if (rc) return rc;
+        } else {
+            if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
+            const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin);
+            float *partial = ws;
+            rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
+                                     mean, invstd, partial, 0, nullptr, stream);
+            if (rc) return rc;
+            rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
+            if (rc) return rc;
+            if (need_dx) {
+                if (training) {
+                    rc = ms3d_bn_bwd_apply(dx, x, Vin, Cin, scale, mean, invstd, dgb, dx, stream);
+                } else {
+                    rc = ms3d_bn_apply(dx, Vin, Cin, scale, nullptr, 0, dx, stream);  // dx = dz * scale
+                }
+                if (rc) return rc;
+            }
+        }
+    }
+    float *slabs = ws + (size_t)ms3d_spconv_partial_blocks(Vin, K, Cout, Cin) * 2 * Cin;
+    return ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs, stream);
 }
 
 }  // extern "C"

@@ -38,8 +38,13 @@ class GeneralModel(nn.Module):
         return self.backbone(data_dict["voxel_features"], data_dict["voxel_xyz"], data_dict["voxel_point_map"])
 
     def _loss(self, data_dict, output_dict):
-        sem = nn.functional.cross_entropy(output_dict["semantic_scores"], data_dict["sem_labels"].long(),
-                                          ignore_index=-1)
+        # cross entropy with ignore_index = -1 (reference general_model.py:39-41), written as log-softmax + gather:
+        # torch's fused nll_loss forward reduces 10^5..10^6 rows in a single block
+        labels = data_dict["sem_labels"].long()
+        valid = labels != -1
+        logp = torch.log_softmax(output_dict["semantic_scores"], dim=1)
+        picked = logp.gather(1, labels.clamp_min(0).unsqueeze(1)).squeeze(1)
+        sem = -(picked * valid).sum() / valid.sum().clamp_min(1)
         gt_offsets = data_dict["instance_center_xyz"] - data_dict["point_xyz"]
         norm_l, dir_l = self.offset_criterion(output_dict["point_offsets"], gt_offsets,
                                               valid_mask=data_dict["instance_ids"] != -1)

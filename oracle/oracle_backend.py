@@ -120,6 +120,31 @@ class OracleBackend:
         xh = (bx - mean) * invstd
         return dz, torch.stack([dz.sum(0), (dz * xh).sum(0)])
 
+    def conv_layer_forward(self, x, W3, nbr_fwd, vout, K, cin, cout, mirror_bwd, pre, pre_relu, residual, bias,
+                           want_stats):
+        wf, wft = self.prep_weights_pair(W3, K, cin, cout, mirror_bwd)
+        res = self.conv_forward(x, wf, nbr_fwd, vout, K, cin, cout, pre=pre, pre_relu=pre_relu, residual=residual,
+                                out_stats=want_stats, bias=bias)
+        y, stats = res if want_stats else (res, None)
+        return y, stats, (wf, wft)
+
+    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx):
+        wft = wf_buf[1]
+        dx = dgb = None
+        if bn is None:
+            if need_dx:
+                dx = self.conv_forward(dy, wft, nbr_bwd, vin, K, cout, cin)
+        else:
+            assert bn["relu"]
+            dz, dgb = self.conv_forward(dy, wft, nbr_bwd, vin, K, cout, cin,
+                                        bn_bwd=(x, bn["scale"], bn["shift"], bn["mean"], bn["invstd"]))
+            if need_dx:
+                dx = (self.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], dgb) if bn["training"]
+                      else dz * bn["scale"])
+        pre = (bn["scale"], bn["shift"]) if bn is not None else None
+        dW = self.conv_backward_weight(x, dy, nbr_fwd, vout, K, cin, cout, pre=pre, pre_relu=bool(bn and bn["relu"]))
+        return dx, dgb, dW
+
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):
         a = self._act(x.detach(), pre, pre_relu)
         return _t(O.conv_bwd_weight(_np(a), _np(dout), _np(nbr).T, K))
