@@ -123,7 +123,8 @@ def main():
 
     timer = None
     if not args.no_roofline:
-        timer = ms_backend.KernelTimer(lambda name, K, cin, cout: name == "spconv_fwd" and K == 27 and cin == 16 and cout == 16)
+        timer = ms_backend.KernelTimer(lambda name, K, cin, cout: name == "spconv_fwd" and K == 27 and cin == 16 and cout == 16,
+                                       be.lib)
         be.kernel_timer = timer
 
     def sync_all():
@@ -167,7 +168,7 @@ def main():
                 ach = s["avg_bytes"] / (s["avg_ms"] * 1e-3) / 1e9
                 line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                    "kernel": "spconv_fwd_kernel<1,true> (k3 16->16 gather/MFMA, fwd + bwd-data)",
+                                    "kernel": "spconv_fwd_kernel<1,true> (3x3x3 16->16 gather/MFMA at full resolution, forward launches)",
                                     "launches": s["launches"], "avg_us": round(s["avg_ms"] * 1e3, 2),
                                     "algorithmic_bytes_per_launch": int(s["avg_bytes"])}
         if world == 1 and not args.no_cpu_baseline:

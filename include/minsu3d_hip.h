@@ -167,7 +167,12 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout);
 int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
                               int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
                               const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
-                              ms3d_stream_t stream);
+                              void *ev_start /* hipEvent_t or NULL */, void *ev_stop, ms3d_stream_t stream);
+/* HIP events for timing a launch on the stream it is issued on (recorded inside ms3d_spconv_layer_forward around
+ * the convolution kernel only) */
+void *ms3d_event_create(void);
+void ms3d_event_destroy(void *event);
+float ms3d_event_elapsed_ms(void *start, void *stop);
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,

@@ -219,13 +219,17 @@ def _f32(t):
 
 
 class KernelTimer:
-    """brackets selected launches with HIP events recorded on the stream the kernels are launched on
-    (torch's current stream) and keeps the algorithmic byte count of each (SURVEY 8d formula)"""
+    """Times selected kernel launches with HIP events recorded INSIDE the library call, immediately before and
+    after the kernel on the stream it is launched on, and keeps the algorithmic byte count of each launch
+    (SURVEY 8d formula with the table's real pair count)."""
 
-    def __init__(self, select):
+    def __init__(self, select, lib):
         self.select = select            # (name, K, cin, cout) -> bool
-        self.records = []               # (start_event, end_event, algorithmic_bytes)
-        self._pairs = {}                # table data_ptr -> number of valid (in, out) pairs
+        self.lib = lib
+        lib.ms3d_event_create.restype = C.c_void_p
+        lib.ms3d_event_elapsed_ms.restype = C.c_float
+        self.records = []               # (start_event, stop_event, algorithmic_bytes)
+        self._pairs = {}                # table -> number of valid (in, out) pairs
         self.enabled = False
 
     def begin(self, name, K, cin, cout, nbr):
@@ -236,20 +240,19 @@ class KernelTimer:
             self._pairs[key] = int((nbr >= 0).sum().item())
         nM = self._pairs[key]
         nbytes = nM * (cin + cout) * 4 + nM * 8 + K * cin * cout * 4
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
-        ev[0].record()
-        return ev
-
-    def end(self, ev, extra_launches=0):
-        ev[1].record()
+        ev = (C.c_void_p(self.lib.ms3d_event_create()), C.c_void_p(self.lib.ms3d_event_create()), nbytes)
         self.records.append(ev)
+        return ev
 
     def summary(self):
         if not self.records:
             return None
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b, _ in self.records]
+        ms = [self.lib.ms3d_event_elapsed_ms(a, b) for a, b, _ in self.records]
         nb = [n for _, _, n in self.records]
+        for a, b, _ in self.records:
+            self.lib.ms3d_event_destroy(a); self.lib.ms3d_event_destroy(b)
+        self.records = []
+        ms = [m for m in ms if m >= 0]
         return dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_bytes=sum(nb) / len(nb))
 
 
@@ -364,15 +367,11 @@ class _HipEngine:
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
         if bn_bwd is not None:
             bnargs = [_f32(t) for t in bn_bwd]
-        timer = self.kernel_timer
-        tok = timer.begin("spconv_fwd", K, cin, cout, nbr) if timer is not None else None
         _lib.check(self.lib.ms3d_spconv_forward(
             _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
             _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
             *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), int(bool(out_stats)), _lib.ptr(_f32(bias)),
             _lib.stream_handle()), "ms3d_spconv_forward")
-        if tok is not None:
-            timer.end(tok)
         if bn_bwd is None:
             return (out, partial) if out_stats else out
         s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)
@@ -398,13 +397,12 @@ class _HipEngine:
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
         tok = timer.begin("spconv_fwd", K, cin, cout, nbr_fwd) if timer is not None else None
+        ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
         _lib.check(self.lib.ms3d_spconv_layer_forward(
             _lib.ptr(x), _lib.ptr(self._dev(W3)), _lib.ptr(nbr_fwd), int(vout), int(K), int(cin), int(cout),
             int(bool(mirror_bwd)), _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
-            _lib.ptr(_f32(bias)), _lib.ptr(wf_buf), _lib.ptr(y), _lib.ptr(stats), _lib.stream_handle()),
+            _lib.ptr(_f32(bias)), _lib.ptr(wf_buf), _lib.ptr(y), _lib.ptr(stats), ev0, ev1, _lib.stream_handle()),
             "ms3d_spconv_layer_forward")
-        if tok is not None:
-            timer.end(tok, extra_launches=1)   # the bracket also contains the tiny weight-permutation launch
         return y, stats, wf_buf
 
     def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx):
@@ -418,10 +416,6 @@ class _HipEngine:
         dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
         dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
-        timer = self.kernel_timer
-        tok = timer.begin("spconv_fwd", K, cout, cin, nbr_bwd) if (timer is not None and want_dx) else None
-        if tok is not None:
-            tok = None   # the backward call brackets several kernels; only the forward bracket is a clean sample
         _lib.check(self.lib.ms3d_spconv_layer_backward(
             _lib.ptr(x), _lib.ptr(dy), _lib.ptr(wf_buf), _lib.ptr(nbr_fwd), _lib.ptr(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _lib.ptr(bn["scale"] if has_bn else None), _lib.ptr(bn["shift"] if has_bn else None),

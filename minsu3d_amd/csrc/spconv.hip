@@ -99,25 +99,40 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
 // ------------------------------------------------------------------ forward / backward-data
 constexpr int OG = 9;  // offsets processed together: 9 neighbour indices, then 9 row gathers in flight per wave
 
+// table entries of offsets [g0, g0+OG) for one row; OR-mask instead of a select: a select lets the compiler sink
+// the load into a branch + vmcnt(0)
+__device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0, int k_hi, int (&idx)[OG])
+{
+    const bool row_ok = row >= 0 && row < p.Vout;
+    const int safe_row = row_ok ? row : 0;
+#pragma unroll
+    for (int u = 0; u < OG; u++) {
+        const int k = min(g0 + u, k_hi - 1);
+        const int v = p.nbr[(size_t)k * p.Vout + safe_row];
+        idx[u] = v | ((row_ok && g0 + u < k_hi) ? 0 : -1);
+    }
+}
+
 // Offsets [k_lo, k_hi) of one 16-row tile.  `kw0` = index of offset k_lo inside the LDS weight image.
-// Loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
+// Software pipeline: on entry `idx_pre` holds the indices of the first group (loaded by the caller / the previous
+// tile); while a group's rows are gathered and multiplied, the NEXT group's indices (or the next tile's first group,
+// `next_row`) are already in flight, so a group costs one dependent memory round trip instead of two.
+// Row loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
 // compiler drain vmcnt(0) before each one, which serialises the whole neighbourhood (measured: 27 x latency).
 template <int NBT, bool ALIGNED>
 __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const float *__restrict__ sW, int k_lo, int k_hi,
-                                                   int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
+                                                   int kw0, int my_row, int next_row, int q, int nb0, f32x4 (&acc)[NBT],
+                                                   int (&idx_pre)[OG])
 {
     const int l = lane_id();
-    const bool row_ok = my_row < p.Vout;
-    const int safe_row = row_ok ? my_row : 0;
     for (int g0 = k_lo; g0 < k_hi; g0 += OG) {
         int idx[OG];
 #pragma unroll
-        for (int u = 0; u < OG; u++) {
-            const int k = min(g0 + u, k_hi - 1);
-            // OR-mask instead of a select: a select lets the compiler sink the load into a branch + vmcnt(0)
-            const int v = p.nbr[(size_t)k * p.Vout + safe_row];
-            idx[u] = v | ((row_ok && g0 + u < k_hi) ? 0 : -1);
-        }
+        for (int u = 0; u < OG; u++) idx[u] = idx_pre[u];
+        if (g0 + OG < k_hi)
+            load_indices(p, my_row, g0 + OG, k_hi, idx_pre);
+        else
+            load_indices(p, next_row, k_lo, k_hi, idx_pre);
         bool any[OG];
 #pragma unroll
         for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
@@ -159,7 +174,7 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 const int keep = ~(idx[u] >> 31);  // absent neighbour (idx < 0) contributes nothing
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
-                if (!any[u]) continue;                                  // wave-uniform: none of the 16 rows has it
+                if (!any[u]) continue;
                 // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
                 const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
 #pragma unroll
@@ -254,13 +269,16 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         const int chunk = (p.ntiles + total_waves - 1) / total_waves;
         const int wglobal = vb * waves + wave_id();
         const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
+        int idx_pre[OG];
+        load_indices(p, t_begin < t_end ? t_begin * 16 + (l & 15) : -1, 0, p.K, idx_pre);
         for (int tile = t_begin; tile < t_end; tile++) {
             const int row0 = tile * 16;
             const int my_row = row0 + (l & 15);
             f32x4 acc[NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
+            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, tile + 1 < t_end ? my_row + 16 : -1, q, nb0, acc,
+                                             idx_pre);
             store_tile<NBT>(p, row0, nb0, acc, s_part);
         }
     } else {
@@ -276,7 +294,11 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             __syncthreads();
             stage(g0, gn);
             __syncthreads();
-            if (tile < p.ntiles) accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, q, nb0, acc);
+            if (tile < p.ntiles) {
+                int idx_pre[OG];
+                load_indices(p, my_row, g0, g0 + gn, idx_pre);
+                accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, -1, q, nb0, acc, idx_pre);
+            }
         }
         if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
@@ -867,13 +889,32 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
 int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
                               int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
                               const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
-                              ms3d_stream_t stream)
+                              void *ev_start, void *ev_stop, ms3d_stream_t stream)
 {
     float *wf = wf_buf, *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     int rc = ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream);
     if (rc) return rc;
-    return ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
-                               nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, stream);
+    // optional HIP events bracketing ONLY the convolution kernel, on the stream it is launched on (bench.py roofline)
+    if (ev_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
+    rc = ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, stream);
+    if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+    return rc;
+}
+
+void *ms3d_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
+}
+void ms3d_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+// milliseconds between two recorded events (synchronises on `stop`); < 0 on error
+float ms3d_event_elapsed_ms(void *start, void *stop)
+{
+    float ms = -1.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
 }
 
 // backward of the fused layer.  need_dx / bn (scale != NULL) select the pieces:
