@@ -114,25 +114,18 @@ __device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0,
 }
 
 // Offsets [k_lo, k_hi) of one 16-row tile.  `kw0` = index of offset k_lo inside the LDS weight image.
-// Software pipeline: on entry `idx_pre` holds the indices of the first group (loaded by the caller / the previous
-// tile); while a group's rows are gathered and multiplied, the NEXT group's indices (or the next tile's first group,
-// `next_row`) are already in flight, so a group costs one dependent memory round trip instead of two.
+// (Prefetching the next group's indices across iterations was measured SLOWER -- 60 -> 70 us on the 16->16 level-0
+// conv -- the extra live registers cost more than the saved round trip; each group loads its own indices.)
 // Row loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
 // compiler drain vmcnt(0) before each one, which serialises the whole neighbourhood (measured: 27 x latency).
 template <int NBT, bool ALIGNED>
 __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const float *__restrict__ sW, int k_lo, int k_hi,
-                                                   int kw0, int my_row, int next_row, int q, int nb0, f32x4 (&acc)[NBT],
-                                                   int (&idx_pre)[OG])
+                                                   int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
 {
     const int l = lane_id();
     for (int g0 = k_lo; g0 < k_hi; g0 += OG) {
         int idx[OG];
-#pragma unroll
-        for (int u = 0; u < OG; u++) idx[u] = idx_pre[u];
-        if (g0 + OG < k_hi)
-            load_indices(p, my_row, g0 + OG, k_hi, idx_pre);
-        else
-            load_indices(p, next_row, k_lo, k_hi, idx_pre);
+        load_indices(p, my_row, g0, k_hi, idx);
         bool any[OG];
 #pragma unroll
         for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
@@ -269,16 +262,13 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         const int chunk = (p.ntiles + total_waves - 1) / total_waves;
         const int wglobal = vb * waves + wave_id();
         const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
-        int idx_pre[OG];
-        load_indices(p, t_begin < t_end ? t_begin * 16 + (l & 15) : -1, 0, p.K, idx_pre);
         for (int tile = t_begin; tile < t_end; tile++) {
             const int row0 = tile * 16;
             const int my_row = row0 + (l & 15);
             f32x4 acc[NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, tile + 1 < t_end ? my_row + 16 : -1, q, nb0, acc,
-                                             idx_pre);
+            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
             store_tile<NBT>(p, row0, nb0, acc, s_part);
         }
     } else {
@@ -294,11 +284,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             __syncthreads();
             stage(g0, gn);
             __syncthreads();
-            if (tile < p.ntiles) {
-                int idx_pre[OG];
-                load_indices(p, my_row, g0, g0 + gn, idx_pre);
-                accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, -1, q, nb0, acc, idx_pre);
-            }
+            if (tile < p.ntiles) accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, q, nb0, acc);
         }
         if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
