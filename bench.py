@@ -166,8 +166,13 @@ def main():
             s = timer.summary()
             if s:
                 ach = s["avg_bytes"] / (s["avg_ms"] * 1e-3) / 1e9
+                traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes of this command
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.exists(tpath):
+                    with open(tpath) as f:
+                        traffic = int(json.load(f)["traffic_bytes_per_launch"])
                 line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                     "kernel": "spconv_fwd_kernel<1,true> (3x3x3 16->16 gather/MFMA at full resolution, forward launches)",
                                     "launches": s["launches"], "avg_us": round(s["avg_ms"] * 1e3, 2),
                                     "algorithmic_bytes_per_launch": int(s["avg_bytes"])}

@@ -118,7 +118,7 @@ __device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0,
 // conv -- the extra live registers cost more than the saved round trip; each group loads its own indices.)
 // Row loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
 // compiler drain vmcnt(0) before each one, which serialises the whole neighbourhood (measured: 27 x latency).
-template <int NBT, bool ALIGNED>
+template <int NBT, bool ALIGNED, bool DIRECT = false>
 __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const float *__restrict__ sW, int k_lo, int k_hi,
                                                    int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
 {
@@ -168,13 +168,24 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
                 if (!any[u]) continue;
-                // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
-                const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
+                if (DIRECT) {
+                    // small levels: B fragments straight from the global image (L2 resident), no LDS staging
+                    const float *w = p.wf + ((size_t)(((g0 + u) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
+                    for (int t = 0; t < 4; t++) {
 #pragma unroll
-                    for (int nb = 0; nb < NBT; nb++)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
+                        for (int nb = 0; nb < NBT; nb++)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
+                    }
+                } else {
+                    // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
+                    const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -296,6 +307,63 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     }
 }
 
+// Small levels (a few hundred to a few thousand rows at the bottom of the U-Net, 64..224 channels): the weight image
+// (0.4 - 1.4 MB) dwarfs the activations, so staging it through LDS per block is the whole cost.  Here one block =
+// one 16-row tile x NBT column blocks, its waves split the K offsets (9 each), read their B fragments directly from
+// the L2-resident global image, and wave 0 sums the partial accumulators through LDS before the usual epilogue.
+template <int NBT, bool ALIGNED>
+__global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    const int l = lane_id(), q = l >> 4;
+    const int waves = blockDim.x >> 6;  // = ceil(K / OG)
+    const int nb0 = blockIdx.y * NBT;
+    float *s_acc = lds;                                        // [(waves-1)][NBT][4][64]
+    float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // [2*Cout] when bn_x / out_stats
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) {
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    }
+    const int tile = blockIdx.x;
+    const int row0 = tile * 16, my_row = row0 + (l & 15);
+    f32x4 acc[NBT];
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int k_lo = wave_id() * OG, k_hi = min(p.K, k_lo + OG);
+    if (k_lo < k_hi) accumulate_offsets<NBT, ALIGNED, true>(p, nullptr, k_lo, k_hi, 0, my_row, q, nb0, acc);
+    if (wave_id() > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_acc[((size_t)(wave_id() - 1) * NBT + nb) * 256 + r * 64 + l] = acc[nb][r];
+    }
+    __syncthreads();
+    if (wave_id() == 0) {
+        for (int w = 1; w < waves; w++)
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[nb][r] += s_acc[((size_t)(w - 1) * NBT + nb) * 256 + r * 64 + l];
+        store_tile<NBT>(p, row0, nb0, acc, s_part);
+    }
+    if (with_partial) {
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT>
+int launch_fwd_small(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
+{
+    if (aligned)
+        spconv_fwd_small_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
+    else
+        spconv_fwd_small_kernel<NBT, false><<<grid, threads, lds, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NBT>
 int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
 {
@@ -349,41 +417,52 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     const int r_begin = blockIdx.x * p.rows_per_block;
     const int r_end = min(p.Vout, r_begin + p.rows_per_block);
     const int nw = blockDim.x >> 6;
-    for (int r0 = r_begin + wave_id() * 4; r0 < r_end; r0 += 4 * nw) {
-        const int row = r0 + q;  // k-slot q of the MFMA <-> row r0 + q
-        const bool row_ok = row < r_end;
-        float b[NBT];
+    // Two independent 4-row steps per trip (rows r0.. and r0 + 4*nw..): all loads of both steps are issued before
+    // the first MFMA, so a trip costs one dependent round trip (index -> row) for 8 rows instead of two.
+    for (int r0 = r_begin + wave_id() * 4; r0 < r_end; r0 += 8 * nw) {
+        int idx[2][KG];
+        float a[2][KG], b[2][NBT];
+        bool ok[2];
 #pragma unroll
-        for (int nb = 0; nb < NBT; nb++) {
-            const int j = 16 * nb + cl;
-            const float v = p.dout[(size_t)(row_ok ? row : r_begin) * p.Cout + (j < p.Cout ? j : 0)];
-            b[nb] = __int_as_float(__float_as_int(v) & ((row_ok && j < p.Cout) ? -1 : 0));
-        }
-        // unconditional loads (clamped addresses, values zeroed afterwards) so all KG gathers are in flight together
-        const int safe_row = row_ok ? row : r_begin;
-        int idx[KG];
+        for (int h = 0; h < 2; h++) {
+            const int row = r0 + h * 4 * nw + q;  // k-slot q of the MFMA <-> row
+            ok[h] = row < r_end;
+            const int safe_row = ok[h] ? row : r_begin;
 #pragma unroll
-        for (int kk = 0; kk < KG; kk++) {
-            const int v = p.nbr[(size_t)min(k0 + kk, p.K - 1) * p.Vout + safe_row];
-            idx[kk] = v | ((k0 + kk < p.K && row_ok) ? 0 : -1);
-        }
-        float a[KG];
-#pragma unroll
-        for (int kk = 0; kk < KG; kk++) a[kk] = p.in[(size_t)max(idx[kk], 0) * p.Cin + c_safe];
-#pragma unroll
-        for (int kk = 0; kk < KG; kk++) {
-            float v = a[kk];
-            if (p.pre_scale) {
-                v = fmaf(v, sc, sh);
-                if (p.pre_relu) v = fmaxf(v, 0.f);
+            for (int nb = 0; nb < NBT; nb++) {
+                const int j = 16 * nb + cl;
+                const float v = p.dout[(size_t)safe_row * p.Cout + (j < p.Cout ? j : 0)];
+                b[h][nb] = __int_as_float(__float_as_int(v) & ((ok[h] && j < p.Cout) ? -1 : 0));
             }
-            a[kk] = __int_as_float(__float_as_int(v) & ~(idx[kk] >> 31) & c_mask);
+            // unconditional loads (clamped addresses, values masked afterwards): all gathers in flight together
+#pragma unroll
+            for (int kk = 0; kk < KG; kk++) {
+                const int v = p.nbr[(size_t)min(k0 + kk, p.K - 1) * p.Vout + safe_row];
+                idx[h][kk] = v | ((k0 + kk < p.K && ok[h]) ? 0 : -1);
+            }
         }
 #pragma unroll
-        for (int kk = 0; kk < KG; kk++) {
-            if (__ballot(idx[kk] >= 0) == 0ull) continue;
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int nb = 0; nb < NBT; nb++) acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b[nb], acc[kk][nb], 0, 0, 0);
+            for (int kk = 0; kk < KG; kk++) a[h][kk] = p.in[(size_t)max(idx[h][kk], 0) * p.Cin + c_safe];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int kk = 0; kk < KG; kk++) {
+                float v = a[h][kk];
+                if (p.pre_scale) {
+                    v = fmaf(v, sc, sh);
+                    if (p.pre_relu) v = fmaxf(v, 0.f);
+                }
+                a[h][kk] = __int_as_float(__float_as_int(v) & ~(idx[h][kk] >> 31) & c_mask);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KG; kk++) {
+                if (__ballot(idx[h][kk] >= 0) == 0ull) continue;
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++)
+                    acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h][kk], b[h][nb], acc[kk][nb], 0, 0, 0);
+            }
         }
     }
     // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl.
@@ -646,8 +725,9 @@ namespace {
 struct FwdGeom {
     int nbt, ny, threads, nblk, G;
     size_t lds;
-    bool ok;
+    bool ok, small;
 };
+constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
 // bottom of the U-Net) are spread over the chip by giving each wave fewer output columns and each block fewer waves.
 FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
@@ -655,6 +735,25 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
     FwdGeom g{};
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int ntiles = ms3d_divup(Vout, 16);
+    if (ntiles <= SMALL_TILES && (size_t)NCH * NBtot >= 4) {
+        // one block per (tile, column slice); waves = offset groups; enough column splits for ~1024+ waves
+        const int ks = ms3d_divup(K, OG);
+        int ny = ms3d_divup(NBtot, MAX_NBT);
+        while (NBtot % ny != 0) ny++;
+        while ((long)ntiles * ny * ks < 1024 && ny < NBtot) {
+            ny++;
+            while (NBtot % ny != 0) ny++;
+        }
+        g.small = true;
+        g.ny = ny;
+        g.nbt = NBtot / ny;
+        g.threads = ks * 64;
+        g.nblk = ntiles;
+        g.G = K;
+        g.lds = ((size_t)(ks - 1) * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
+        g.ok = ks <= 4 && g.nbt >= 1 && g.nbt <= MAX_NBT;
+        return g;
+    }
     int ny = ms3d_divup(NBtot, MAX_NBT);
     while (NBtot % ny != 0) ny++;
     while ((long)ntiles * ny < 1024 && ny < NBtot) {  // more column splits until ~4 waves per CU exist
@@ -670,7 +769,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
         g.G = K;
         const size_t need = per_offset * K + extra;
         int threads = need <= 32 * 1024 ? 256 : (need <= 76 * 1024 ? 512 : 1024);
-        while (threads > 128 && (long)ms3d_divup(ntiles, threads / 64) * ny < 512) threads >>= 1;  // few tiles: more blocks
+        while (threads > 128 && (long)ms3d_divup(ntiles, threads / 64) * ny < 128) threads >>= 1;  // few tiles: more blocks
         g.threads = threads;
         g.nblk = ms3d_divup(ntiles, threads / 64);
         if (g.nblk > 1024) g.nblk = 1024;
@@ -719,6 +818,19 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
+    if (g.small) {
+        switch (g.nbt) {
+            case 1: return launch_fwd_small<1>(p, grid, g.threads, g.lds, aligned, stream);
+            case 2: return launch_fwd_small<2>(p, grid, g.threads, g.lds, aligned, stream);
+            case 3: return launch_fwd_small<3>(p, grid, g.threads, g.lds, aligned, stream);
+            case 4: return launch_fwd_small<4>(p, grid, g.threads, g.lds, aligned, stream);
+            case 5: return launch_fwd_small<5>(p, grid, g.threads, g.lds, aligned, stream);
+            case 6: return launch_fwd_small<6>(p, grid, g.threads, g.lds, aligned, stream);
+            case 7: return launch_fwd_small<7>(p, grid, g.threads, g.lds, aligned, stream);
+            case 8: return launch_fwd_small<8>(p, grid, g.threads, g.lds, aligned, stream);
+        }
+        return MS3D_E_UNSUPPORTED;
+    }
     switch (g.nbt) {
         case 1: return launch_fwd<1>(p, grid, g.threads, g.lds, aligned, stream);
         case 2: return launch_fwd<2>(p, grid, g.threads, g.lds, aligned, stream);
