@@ -115,7 +115,7 @@ def main():
     be = ms_backend.get_backend()          # raises if libminsu3d_hip.so is missing: no fallback
 
     model = build(cfg, device)
-    ddp = wrap_ddp(model, device)
+    ddp = wrap_ddp(model, device, find_unused_parameters=False)   # grouping branch on: every parameter gets a gradient
     opt = model.configure_optimizers()
     batches = [make_batch(shard_scene_seeds(s, args.batch, rank, world), device) for s in range(args.pool)]
     n_pts = float(np.mean([b["point_xyz"].shape[0] for b in batches])) / args.batch

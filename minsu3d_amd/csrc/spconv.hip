@@ -21,6 +21,7 @@
 //              BN and accumulates the two BN-backward channel sums in its epilogue.
 // Backward-weight is a second kernel: dW[k] = sum_i act(in[nbr[k][i]])^T dout[i] on the same MFMA, rows as
 // the reduction dimension, several offsets per wave sharing the dout fragment.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/minsu3d_hip.h"
 
@@ -735,7 +736,11 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
     FwdGeom g{};
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int ntiles = ms3d_divup(Vout, 16);
-    if (ntiles <= SMALL_TILES && (size_t)NCH * NBtot >= 4) {
+    static const int small_tiles = [] {
+        const char *e = getenv("MS3D_SMALL_TILES");  // tuning knob; default measured on MI355X
+        return e ? atoi(e) : SMALL_TILES;
+    }();
+    if (ntiles <= small_tiles && (size_t)NCH * NBtot >= 4) {
         // one block per (tile, column slice); waves = offset groups; enough column splits for ~1024+ waves
         const int ks = ms3d_divup(K, OG);
         int ny = ms3d_divup(NBtot, MAX_NBT);
