@@ -54,6 +54,12 @@ int ms3d_sg_bfs_cluster(const float *class_numpoint_mean /*[host]*/, const int *
                         int *cluster_offsets, int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes,
                         ms3d_stream_t stream);
 
+/* all SoftGroup classes in one call: group_of_point u8[N] (class*B + scene, non-decreasing), thr_per_group f32[G]
+ * (device); output clusters are class-major = the reference's per-class concatenation (model/softgroup.py:43-83) */
+int ms3d_sg_bfs_cluster_batched(const uint8_t *group_of_point, const float *thr_per_group, const int *ball_query_idxs,
+                                long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets,
+                                int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
+
 /* ---- HAIS: replaces hierarchical_aggregation, hierarchical_aggregation/hierarchical_aggregation.h:14-28
  * (host .cpp:8-184 + .cu:20-204) AND the kept/primary merge of functions/hais_ops.py:55-73: the output is the final
  * (cluster_idxs, cluster_offsets) pair -- kept fragments first, then primaries with their absorbed fragments

@@ -117,6 +117,11 @@ class HipBackend:
         return self._bfs("ms3d_sg_bfs_cluster", (mean,), ball_query_idxs, start_len,
                          (C.c_float(threshold), int(class_id)))
 
+    def sg_bfs_cluster_batched(self, group_of_point, thr_per_group, ball_query_idxs, start_len):
+        g = self._dev(group_of_point); t = self._dev(thr_per_group)
+        assert g.dtype == torch.uint8 and t.dtype == torch.float32
+        return self._bfs("ms3d_sg_bfs_cluster_batched", (_lib.ptr(g), _lib.ptr(t)), ball_query_idxs, start_len, ())
+
     def hierarchical_aggregation(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
                                  point_num_avg, radius_avg, ignored_label=-1):
         sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)

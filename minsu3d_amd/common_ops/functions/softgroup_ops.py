@@ -11,6 +11,12 @@ def sg_bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, threshold, c
                                             int(class_id))
 
 
+def sg_bfs_cluster_batched(group_of_point, thr_per_group, ball_query_idxs, start_len):
+    """every class of SoftGroup's grouping loop in one call (see include/minsu3d_hip.h); same output contract"""
+    with torch.no_grad():
+        return get_backend().sg_bfs_cluster_batched(group_of_point, thr_per_group, ball_query_idxs, start_len)
+
+
 class _GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, proposals_offset):

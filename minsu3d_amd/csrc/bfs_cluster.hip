@@ -34,13 +34,19 @@ constexpr int BFS_WAVES = BFS_THREADS / 64;
 constexpr int INT_BIG = 0x7fffffff;
 
 struct Thr {
-    int mode;     // 0 = pg (label test, int threshold), 1 = sg (no label test, float threshold)
+    int mode;     // 0 = pg (label test, int threshold), 1 = sg (no label test, float threshold),
+                  // 2 = sg batched over classes: float threshold looked up through the seed's group id
     int thr_i;
     float thr_f;
+    const uint8_t *group;     // mode 2: group (class*B + scene) of every point
+    const float *thr_group;   // mode 2: threshold of every group
 };
-__device__ __forceinline__ bool qualifies(const Thr &t, int size)
+// `node` = the cluster's seed (any member works: a cluster never leaves its group)
+__device__ __forceinline__ bool qualifies(const Thr &t, int size, int node)
 {
-    return t.mode == 0 ? (size >= t.thr_i) : ((float)size >= t.thr_f);  // bfs_cluster.cpp:94 / :121
+    if (t.mode == 0) return size >= t.thr_i;                      // bfs_cluster.cpp:94
+    if (t.mode == 1) return (float)size >= t.thr_f;                // bfs_cluster.cpp:121
+    return (float)size >= t.thr_group[t.group[node]];
 }
 
 __device__ __forceinline__ int ld_agent(const int *p)
@@ -132,7 +138,7 @@ __global__ void bfs_select_kernel(int N, Thr thr, const int *__restrict__ root, 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    if (root[i] == i && qualifies(thr, comp_size[i])) worklist[atomicAdd(&counters[0], 1)] = i;
+    if (root[i] == i && qualifies(thr, comp_size[i], i)) worklist[atomicAdd(&counters[0], 1)] = i;
 }
 
 __device__ __forceinline__ int block_excl_scan_512(int v, int *total, int *s_wave)
@@ -420,7 +426,7 @@ __global__ void bfs_keep_kernel(int N, Thr thr, const int *__restrict__ cl_size,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int s = cl_size[i];
-    const int k = (s > 0 && qualifies(thr, s)) ? 1 : 0;
+    const int k = (s > 0 && qualifies(thr, s, i)) ? 1 : 0;
     keep[i] = k;
     keep_size[i] = k ? s : 0;
 }
@@ -574,7 +580,7 @@ int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, 
                           const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
                           void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    Thr thr{mode, thr_i, thr_f};
+    Thr thr{mode, thr_i, thr_f, nullptr, nullptr};
     return bfs_run(thr, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, stream);
 }
@@ -591,7 +597,7 @@ int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idx
                         int N, int threshold, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
                         size_t workspace_bytes, ms3d_stream_t stream)
 {
-    Thr thr{0, threshold, 0.f};
+    Thr thr{0, threshold, 0.f, nullptr, nullptr};
     return bfs_run(thr, semantic_label, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts,
                    workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -601,7 +607,21 @@ int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
 {
     const float m = class_numpoint_mean[class_id];  // bfs_cluster.cpp:113-120
-    Thr thr{1, 0, (m == -1.f) ? threshold : threshold * m};
+    Thr thr{1, 0, (m == -1.f) ? threshold : threshold * m, nullptr, nullptr};
+    return bfs_run(thr, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+                   workspace_bytes, (hipStream_t)stream);
+}
+
+
+// SoftGroup's per-class loop (model/softgroup.py:43-76) as ONE launch sequence: the caller concatenates the points of
+// all classes in class order, ball-queries them with group id = class*B + scene, and passes each group's threshold
+// (threshold or threshold*class_numpoint_mean[class], bfs_cluster.cpp:113-120).  Clusters come out by ascending seed,
+// i.e. class-major -- exactly the order in which the reference concatenates its per-class results.
+int ms3d_sg_bfs_cluster_batched(const uint8_t *group_of_point, const float *thr_per_group, const int *ball_query_idxs,
+                                long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets,
+                                int *counts, void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
+{
+    Thr thr{2, 0, 0.f, group_of_point, thr_per_group};
     return bfs_run(thr, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, (hipStream_t)stream);
 }

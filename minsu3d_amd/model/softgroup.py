@@ -21,7 +21,8 @@ class SoftGroup(GeneralModel):
         self.iou_score = nn.Linear(m, k)
         self.voxelization_rand = None
 
-    def _soft_grouping(self, data_dict, sem_scores, offsets):
+    def _soft_grouping_loop(self, data_dict, sem_scores, offsets):
+        """the reference's formulation: one ball query + BFS per class (kept as the parity reference of the batched path)"""
         cfg = self.hparams.cfg
         net = cfg.model.network
         idx_parts, off_parts, n_prop, n_rows = [], [], 0, 0
@@ -50,12 +51,46 @@ class SoftGroup(GeneralModel):
         if not idx_parts:                                # the reference raises on torch.cat([]) here
             dev = sem_scores.device
             return torch.zeros((0, 2), dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
-        proposals_idx, proposals_offset = torch.cat(idx_parts, 0), torch.cat(off_parts).int()
-        cap = net.train_cfg.max_proposal_num
+        return self._cap(torch.cat(idx_parts, 0), torch.cat(off_parts).int())
+
+    def _cap(self, proposals_idx, proposals_offset):
+        cap = self.hparams.cfg.model.network.train_cfg.max_proposal_num
         if proposals_offset.numel() > cap:               # reference softgroup.py:80-83 (keeps `cap` proposals)
             proposals_offset = proposals_offset[:cap + 1]
             proposals_idx = proposals_idx[:int(proposals_offset[-1])]
         return proposals_idx, proposals_offset.contiguous()
+
+    def _soft_grouping(self, data_dict, sem_scores, offsets):
+        """All classes at once: the (class, point) pairs above the score threshold are laid out class-major, ball-queried
+        with group id = class*B + scene and clustered by ONE order-exact BFS with per-group thresholds.  Seeds ascend,
+        so the clusters arrive in exactly the order the per-class loop concatenates them."""
+        cfg = self.hparams.cfg
+        net = cfg.model.network
+        dev = sem_scores.device
+        C_ = cfg.data.classes
+        B = int(data_dict["vert_batch_ids"].max().item()) + 1 if data_dict["vert_batch_ids"].numel() else 1
+        if C_ * B > 255:                                  # group ids are uint8 like the reference's batch ids
+            return self._soft_grouping_loop(data_dict, sem_scores, offsets)
+        mask = sem_scores > net.grouping_cfg.score_thr                      # [N, C]
+        for cls in cfg.data.ignore_classes:
+            mask[:, cls - 1] = False
+        mask &= (mask.sum(0) >= net.test_cfg.min_npoint)[None, :]           # classes with too few points are skipped
+        cls_id, pt = mask.t().nonzero(as_tuple=True)                        # class-major, points ascending inside
+        if pt.numel() == 0:
+            return torch.zeros((0, 2), dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        group = (cls_id * B + data_dict["vert_batch_ids"][pt].long()).to(torch.uint8)
+        group_offsets = torch.cumsum(torch.bincount(group.long() + 1, minlength=C_ * B + 1), dim=0).int()
+        shifted = (data_dict["point_xyz"][pt] + offsets[pt]).detach().contiguous()
+        idx, start_len = common_ops.ballquery_batch_p(shifted, group, group_offsets, net.grouping_cfg.radius,
+                                                      net.grouping_cfg.mean_active)
+        mean = torch.tensor(cfg.data.point_num_avg, dtype=torch.float32, device=dev)
+        thr_cls = torch.where(mean == -1, torch.full_like(mean, net.grouping_cfg.npoint_thr),
+                              mean * net.grouping_cfg.npoint_thr)           # bfs_cluster.cpp:113-120
+        thr_group = thr_cls.repeat_interleave(B).contiguous()
+        p_idx, p_off = softgroup_ops.sg_bfs_cluster_batched(group, thr_group, idx, start_len)
+        p_idx = p_idx.long()
+        p_idx[:, 1] = pt[p_idx[:, 1]]
+        return self._cap(p_idx, p_off)
 
     def forward(self, data_dict):
         out = super().forward(data_dict)

@@ -36,6 +36,20 @@ class OracleBackend:
         a, b = O.sg_bfs_cluster(np.asarray(mean, np.float32), _np(idx), _np(start_len), threshold, class_id)
         return _t(a.reshape(-1, 2)), _t(b)
 
+    def sg_bfs_cluster_batched(self, group_of_point, thr_per_group, idx, start_len):
+        """checker for the batched SoftGroup grouping: BFS without threshold, then the per-group float test"""
+        a, b = O.sg_bfs_cluster(np.array([-1.0], np.float32), _np(idx), _np(start_len), 0.0, 0)
+        g, t = _np(group_of_point), _np(thr_per_group)
+        sizes = np.diff(b)
+        seeds = a.reshape(-1, 2)[b[:-1], 1] if sizes.size else np.zeros(0, np.int64)
+        keep = sizes.astype(np.float32) >= t[g[seeds]] if sizes.size else np.zeros(0, bool)
+        rows = np.repeat(keep, sizes)
+        out = a.reshape(-1, 2)[rows].copy()
+        new_id = np.cumsum(keep) - 1
+        out[:, 0] = np.repeat(new_id[keep], sizes[keep])
+        off = np.concatenate([[0], np.cumsum(sizes[keep])]).astype(np.int32)
+        return _t(out.astype(np.int32)), _t(off)
+
     def hierarchical_aggregation(self, sem, coord_shift, idx, start_len, batch_idxs, using_set_aggr, pna, ra,
                                  ignored_label):
         a, b = O.hierarchical_aggregation(_np(sem), _np(coord_shift), _np(idx), _np(start_len), _np(batch_idxs),

@@ -182,6 +182,9 @@ def test_softgroup_step_cpu(cpu_backend):
     out = model(batch)
     P = out["proposals_offset"].numel() - 1
     assert 1 <= P <= 200 and out["cls_scores"].shape == (P, 19) and out["iou_scores"].shape == (P, 19)
+    # the batched grouping (one ball query + one BFS for all classes) == the reference's per-class loop
+    li, lo = model._soft_grouping_loop(batch, sem, batch["grouping_point_offsets"])
+    assert torch.equal(li, out["proposals_idx"]) and torch.equal(lo, out["proposals_offset"])
     assert out["mask_scores"].shape == (out["proposals_idx"].size(0), 19)
     losses = model._loss(batch, out)
     assert {"classification_loss", "mask_scoring_loss", "iou_scoring_loss"} <= set(losses)

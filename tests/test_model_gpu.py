@@ -114,3 +114,21 @@ def test_hais_softgroup_forward_hip_vs_oracle(name):
         assert rel(out_h["cls_scores"], out_r["cls_scores"]) < 5e-3
     for k in loss_r:
         assert abs(float(loss_h[k].detach()) - float(loss_r[k].detach())) < 3e-3 * max(1.0, abs(float(loss_r[k].detach()))), k
+
+
+def test_softgroup_batched_grouping_equals_per_class_loop_on_device():
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from test_model_cpu import _build
+    backend.set_backend(HipBackend())
+    m = _build("softgroup", seed=4).cuda()
+    m.hparams.cfg.data.point_num_avg = [-1, -1] + [400.0] * 18
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((13, 14)).items()}
+    n = b["point_xyz"].size(0)
+    sem = torch.full((n, 20), 0.01, device="cuda")
+    lab = b["grouping_semantic_preds"].long()
+    sem[torch.arange(n, device="cuda"), lab] = 0.8
+    sem[torch.arange(n, device="cuda"), (lab + 3) % 20] = 0.3
+    a1, o1 = m._soft_grouping_loop(b, sem, b["grouping_point_offsets"])
+    a2, o2 = m._soft_grouping(b, sem, b["grouping_point_offsets"])
+    assert o1.numel() > 3 and torch.equal(a1, a2) and torch.equal(o1, o2)
