@@ -400,7 +400,7 @@ struct WgradArgs {
 template <int KG, int NBT>
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
 {
-    __shared__ float s_red[3][64 * 4];  // waves 1..3 hand one accumulator (4 regs x 64 lanes) to wave 0
+    __shared__ float s_red[4 * NBT * 256];  // every wave parks the NBT accumulators of one offset (4 regs x 64 lanes each)
     const int l = lane_id(), q = l >> 4, cl = l & 15;
     const int k0 = blockIdx.y * KG;
     const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A element
@@ -467,28 +467,24 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
         }
     }
     // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl.
-    // Sum the block's waves through LDS in a fixed order, then one plain store per element per block.
+    // Cross-wave sum through LDS, one offset (NBT accumulators) per barrier pair, all threads take part in the sum;
+    // fixed wave order -> deterministic.  One plain store per element per block.
     float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
 #pragma unroll
     for (int kk = 0; kk < KG; kk++) {
         const int k = k0 + kk;
+        __syncthreads();
 #pragma unroll
-        for (int nb = 0; nb < NBT; nb++) {
-            __syncthreads();
-            if (wave_id() > 0) {
+        for (int nb = 0; nb < NBT; nb++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) s_red[wave_id() - 1][r * 64 + l] = acc[kk][nb][r];
-            }
-            __syncthreads();
-            if (wave_id() == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = acc[kk][nb][r];
-                    for (int w = 1; w < nw; w++) v += s_red[w - 1][r * 64 + l];
-                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
-                    if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
-                }
-            }
+            for (int r = 0; r < 4; r++) s_red[(wave_id() * NBT + nb) * 256 + r * 64 + l] = acc[kk][nb][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < NBT * 256; e += blockDim.x) {
+            float v = 0.f;
+            for (int w = 0; w < nw; w++) v += s_red[w * NBT * 256 + e];
+            const int nb = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+            const int ci = blockIdx.z * 16 + 4 * (ln >> 4) + r, j = 16 * nb + (ln & 15);
+            if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
         }
     }
 }
