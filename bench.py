@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--pool", type=int, default=3, help="distinct pre-generated batches per rank (cycled)")
     ap.add_argument("--model", default="pointgroup", choices=["pointgroup", "hais", "softgroup"],
                     help="headline metric = pointgroup; hais / softgroup are the other BASELINE configs")
+    ap.add_argument("--density", type=float, default=1700.0,
+                    help="points per m^2 of the synthetic scenes (1700 = the ~150k-point headline workload; small "
+                         "values expose the host launch floor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +120,8 @@ def main():
     model = build(cfg, device)
     ddp = wrap_ddp(model, device, find_unused_parameters=False)   # grouping branch on: every parameter gets a gradient
     opt = model.configure_optimizers()
-    batches = [make_batch(shard_scene_seeds(s, args.batch, rank, world), device) for s in range(args.pool)]
+    scene_kwargs = None if args.density == 1700.0 else {"density": args.density}
+    batches = [make_batch(shard_scene_seeds(s, args.batch, rank, world), device, scene_kwargs) for s in range(args.pool)]
     n_pts = float(np.mean([b["point_xyz"].shape[0] for b in batches])) / args.batch
     n_vox = float(np.mean([b["voxel_xyz"].shape[0] for b in batches])) / args.batch
 

@@ -180,29 +180,35 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
         }
         int nhits = 0;
         int wlo = 0x7fffffff, whi = -1;  // bitmap words touched by this query (bitmap path only)
-        for (int t0 = 0; t0 < total; t0 += 64) {
-            const int t = t0 + l;
-            bool hit = false;
-            int k = 0;
-            if (t < total) {
-                const float4 p = cell_pts[candidate_pos(t, s_prefix, s_start)];
-                const float dx = ox - p.x, dy = oy - p.y, dz = oz - p.z;
+        // four 64-candidate slices per trip: the four L2 loads of a lane are issued together (one dependent load per
+        // trip made this loop latency-bound: ~1000 cycles per 64 candidates), then consumed in candidate order
+        for (int t0 = 0; t0 < total; t0 += 256) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u + l;
+                p[u] = cell_pts[candidate_pos(min(t, total - 1), s_prefix, s_start)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u + l;
+                const float dx = ox - p[u].x, dy = oy - p[u].y, dz = oz - p[u].z;
                 const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-                hit = d2 < r2;
-                k = __float_as_int(p.w);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (FILL && hit) {
-                if (small)
-                    s_hits[nhits + ballot_rank(m)] = k;
-                else {
-                    const int w = (k - sbeg) >> 5;
-                    atomicOr(&s_bits[w], 1u << ((k - sbeg) & 31));
-                    wlo = min(wlo, w);
-                    whi = max(whi, w);
+                const bool hit = (t < total) && (d2 < r2);
+                const int k = __float_as_int(p[u].w);
+                const unsigned long long m = __ballot(hit);
+                if (FILL && hit) {
+                    if (small)
+                        s_hits[nhits + ballot_rank(m)] = k;
+                    else {
+                        const int w = (k - sbeg) >> 5;
+                        atomicOr(&s_bits[w], 1u << ((k - sbeg) & 31));
+                        wlo = min(wlo, w);
+                        whi = max(whi, w);
+                    }
                 }
+                nhits += __popcll(m);
             }
-            nhits += __popcll(m);
         }
         if (!FILL) {
             if (l == 0) len[i] = min(nhits, BQ_CAP);
