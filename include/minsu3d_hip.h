@@ -90,6 +90,11 @@ int ms3d_global_avg_pool_fp(int nProposal, int C, const float *feats, const int 
 int ms3d_global_avg_pool_bp(int nProposal, int C, float *d_feats, const int *proposals_offset,
                             const float *d_output_feats, ms3d_stream_t stream);
 
+/* dst[idx[i], :] += src[i, :] (dst pre-zeroed by the caller): backward of the row gathers features[v2p_map],
+ * feats[c_idxs], features[p2v_map] (reference backbone.py:40, general_model.py:156, pointgroup.py:88) */
+int ms3d_scatter_add_rows(const float *src, const long long *idx /* int64 */, long n, int C, float *dst,
+                          ms3d_stream_t stream);
+
 /* ---- IoU family: replace get_iou_cuda (get_iou/get_iou.h:16, get_iou.cu:12-38) and
  * get_mask_iou_on_cluster_cuda / get_mask_iou_on_pred_cuda / get_mask_label_cuda
  * (cal_iou_and_masklabel/cal_iou_and_masklabel.h:28-47, .cu:14-140).  One LDS histogram per

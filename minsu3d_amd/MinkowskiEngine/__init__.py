@@ -10,3 +10,4 @@ from . import utils  # noqa: F401
 from .tensor import SparseTensor, CoordinateManager, cat  # noqa: F401
 from .modules import (MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,  # noqa: F401
                       MinkowskiReLU)
+from .functional import gather_rows  # noqa: F401  (engine extra: x[idx] with a scatter-add backward)

@@ -126,3 +126,40 @@ class DenseLinearFn(torch.autograd.Function):
 
 def dense_linear(x, weight, bias):
     return DenseLinearFn.apply(x, weight, bias)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """y = x[idx] with a many-to-one index (voxel -> points).  torch's backward (index_put_ with accumulate) sorts the
+    indices on every call; here the backward is one scatter-add kernel."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = x.size(0)
+        return x[idx]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return get_backend().scatter_add_rows(dy.contiguous(), idx, ctx.n_rows), None
+
+
+class PermuteRowsFn(torch.autograd.Function):
+    """y = x[inv] for a PERMUTATION inv (perm = its inverse): the backward is the gather dy[perm], no accumulation"""
+
+    @staticmethod
+    def forward(ctx, x, inv, perm):
+        ctx.save_for_backward(perm)
+        return x[inv]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (perm,) = ctx.saved_tensors
+        return dy[perm], None, None
+
+
+def gather_rows(x, idx):
+    """differentiable x[idx] for 2-D float features and an int64 row index"""
+    if x.dim() == 2 and idx.dim() == 1 and idx.dtype == torch.int64 and x.requires_grad:
+        return GatherRowsFn.apply(x, idx)
+    return x[idx]

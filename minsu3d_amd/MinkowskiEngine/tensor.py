@@ -87,7 +87,7 @@ class SparseTensor:
         if inv is None:
             return self._F
         if self._F_ext is None:
-            self._F_ext = self._F[inv]
+            self._F_ext = Fn.PermuteRowsFn.apply(self._F, inv, self.coordinate_manager.perm)
         return self._F_ext
 
     F = features

@@ -183,6 +183,15 @@ class HipBackend:
         _lib.check(rc, "ms3d_global_avg_pool_bp")
         return d_feats
 
+    def scatter_add_rows(self, src, idx, n_rows):
+        """dst[idx[i]] += src[i] -> dst [n_rows, C]; float atomics (order-dependent rounding, within fp32 noise)"""
+        src = self._dev(src); idx = self._dev(idx)
+        assert idx.dtype == torch.int64
+        dst = torch.zeros((n_rows, src.size(1)), dtype=torch.float32, device=src.device)
+        _lib.check(self.lib.ms3d_scatter_add_rows(_lib.ptr(src), _lib.ptr(idx), C.c_long(src.size(0)), int(src.size(1)),
+                                                  _lib.ptr(dst), _lib.stream_handle()), "ms3d_scatter_add_rows")
+        return dst
+
     # ------------------------------------------------------------------ IoU family
     def _iou(self, fn_name, prop_idx, prop_off, inst_labels, inst_pointnum, sigmoid=None):
         prop_idx = self._dev(prop_idx); prop_off = self._dev(prop_off)

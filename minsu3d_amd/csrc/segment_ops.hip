@@ -128,6 +128,72 @@ __global__ __launch_bounds__(256) void seg_extreme_kernel(int P, int C, const fl
     }
 }
 
+// Feature rows (C = 16 / 32 / 64, a power of two): one 512-thread block per proposal.  Lanes = (row slot, channel) so
+// every wave load is 256 contiguous bytes; the 8 waves stride the proposal's rows, then combine through LDS with the
+// same "strictly better, or equal and earlier row" rule, which reproduces the serial first-extremum semantics.
+template <bool IS_MAX, bool WITH_ARG>
+__global__ __launch_bounds__(512) void seg_extreme_block_kernel(int P, int C, const float *__restrict__ inp,
+                                                                const int *__restrict__ offsets, float *__restrict__ out,
+                                                                int *__restrict__ arg)
+{
+    __shared__ float s_v[8][64];
+    __shared__ int s_i[8][64];
+    const int w = wave_id(), l = lane_id();
+    const float ident = IS_MAX ? -INFINITY : INFINITY;
+    const int c = l & (C - 1), rsub = l / C, rstep = 64 / C;
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        const int s = offsets[p], e = offsets[p + 1];
+        float best = ident;
+        int bi = -1;
+        for (int r = s + w * rstep + rsub; r < e; r += 8 * rstep) {   // ascending rows per lane
+            const float v = inp[(size_t)r * C + c];
+            if (IS_MAX ? (v > best) : (v < best)) {
+                best = v;
+                bi = r;
+            }
+        }
+        for (int d = 32; d >= C; d >>= 1) {
+            const float ov = __shfl_xor(best, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            const bool better = IS_MAX ? (ov > best) : (ov < best);
+            const bool tie = (ov == best) && (oi >= 0) && (bi < 0 || oi < bi);
+            if (better || tie) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        s_v[w][l] = best;
+        s_i[w][l] = bi;
+        __syncthreads();
+        if (w == 0 && l < C) {
+            for (int k = 1; k < 8; k++) {
+                const float ov = s_v[k][l];
+                const int oi = s_i[k][l];
+                const bool better = IS_MAX ? (ov > best) : (ov < best);
+                const bool tie = (ov == best) && (oi >= 0) && (bi < 0 || oi < bi);
+                if (better || tie) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            out[(size_t)p * C + c] = best;
+            if (WITH_ARG) arg[(size_t)p * C + c] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+// dst[idx[i], :] += src[i, :]  (float atomics: the backward of a many-to-one row gather F[idx])
+__global__ void scatter_add_rows_kernel(const float *__restrict__ src, const long long *__restrict__ idx, long n, int C,
+                                        float *__restrict__ dst)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    const long i = t / C;
+    const int c = (int)(t - i * C);
+    atomicAdd(&dst[(size_t)idx[i] * C + c], src[t]);
+}
+
 __global__ void roipool_bp_kernel(int P, int C, float *__restrict__ d_feats, const int *__restrict__ maxidx,
                                   const float *__restrict__ d_out)
 {
@@ -157,6 +223,7 @@ __global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, float *_
 }
 
 inline int grid_for(int P) { return max(1, min(ms3d_divup(P, WAVES_PER_BLOCK), 4096)); }
+inline bool use_block_kernel(int C) { return (C & (C - 1)) == 0 && C >= 8 && C <= 64; }
 
 }  // namespace
 
@@ -172,14 +239,20 @@ int ms3d_sec_mean(int P, int C, const float *inp, const int *offsets, float *out
 int ms3d_sec_min(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
 {
     if (P <= 0 || C <= 0) return 0;
-    seg_extreme_kernel<false, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    if (use_block_kernel(C))
+        seg_extreme_block_kernel<false, false><<<P < 4096 ? P : 4096, 512, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    else
+        seg_extreme_kernel<false, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
 int ms3d_sec_max(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
 {
     if (P <= 0 || C <= 0) return 0;
-    seg_extreme_kernel<true, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    if (use_block_kernel(C))
+        seg_extreme_block_kernel<true, false><<<P < 4096 ? P : 4096, 512, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
+    else
+        seg_extreme_kernel<true, false><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out, nullptr);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -187,7 +260,10 @@ int ms3d_roipool_fp(int P, int C, const float *feats, const int *offsets, float 
                     ms3d_stream_t stream)
 {
     if (P <= 0 || C <= 0) return 0;
-    seg_extreme_kernel<true, true><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out, maxidx);
+    if (use_block_kernel(C))
+        seg_extreme_block_kernel<true, true><<<P < 4096 ? P : 4096, 512, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out, maxidx);
+    else
+        seg_extreme_kernel<true, true><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out, maxidx);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -200,6 +276,14 @@ int ms3d_roipool_bp(int P, int C, float *d_feats, const int *offsets, const int 
     MS3D_LAUNCH_CHECK();
     return 0;
 }
+int ms3d_scatter_add_rows(const float *src, const long long *idx, long n, int C, float *dst, ms3d_stream_t stream)
+{
+    if (n <= 0 || C <= 0) return 0;
+    scatter_add_rows_kernel<<<ms3d_divup(n * C, 256), 256, 0, (hipStream_t)stream>>>(src, idx, n, C, dst);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int ms3d_global_avg_pool_fp(int P, int C, const float *feats, const int *offsets, float *out,
                             ms3d_stream_t stream)
 {

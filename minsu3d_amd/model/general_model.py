@@ -74,7 +74,7 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
     (injected by parity tests).  -> (SparseTensor over proposal voxels, point->voxel map)"""
     cluster_of = clusters_idx[:, 0].long()
     point_of = clusters_idx[:, 1].long()
-    feats = feats[point_of]
+    feats = ME.gather_rows(feats, point_of)
     xyz = coords[point_of]
     xyz = xyz - common_ops.sec_mean(xyz.contiguous(), clusters_offset)[cluster_of]
     lo = common_ops.sec_min(xyz.contiguous(), clusters_offset)

@@ -34,7 +34,7 @@ class Backbone(nn.Module):
 
     def forward(self, voxel_features, voxel_coordinates, v2p_map):
         x = ME.SparseTensor(features=voxel_features, coordinates=voxel_coordinates)
-        point_features = self.unet(x).features[v2p_map]          # voxel -> point broadcast
+        point_features = ME.gather_rows(self.unet(x).features, v2p_map)   # voxel -> point broadcast
         return {"point_features": point_features,
                 "semantic_scores": self.semantic_branch(point_features),
                 "point_offsets": self.offset_branch(point_features)}

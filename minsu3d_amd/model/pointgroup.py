@@ -5,6 +5,7 @@ host memory for its serial BFS, pointgroup.py:41-66)."""
 import torch
 import torch.nn as nn
 
+from .. import MinkowskiEngine as ME
 from ..common_ops.functions import common_ops, pointgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores
 from .module import TinyUnet
@@ -65,7 +66,7 @@ class PointGroup(GeneralModel):
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"],
                                          data_dict["point_xyz"], net.score_scale, net.score_fullscale, self.device,
                                          rand=self.voxelization_rand)
-        score_feats = self.score_net(vox).features[p2v]                       # (sumNPoint, m)
+        score_feats = ME.gather_rows(self.score_net(vox).features, p2v)      # (sumNPoint, m)
         pooled = common_ops.roipool(score_feats, proposals_offset)            # (nProposal, m)
         out["proposal_scores"] = (self.score_branch(pooled), proposals_idx, proposals_offset)
         return out

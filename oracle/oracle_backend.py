@@ -68,6 +68,10 @@ class OracleBackend:
 
     def roipool_bp(self, d_out, off, maxidx, n): return _t(O.roipool_bp(_np(d_out), _np(off), _np(maxidx), n))
     def global_avg_pool_bp(self, d_out, off, n): return _t(O.global_avg_pool_bp(_np(d_out), _np(off), n))
+    def scatter_add_rows(self, src, idx, n_rows):
+        dst = torch.zeros((n_rows, src.size(1)), dtype=torch.float32)
+        return dst.index_add_(0, idx, src)
+
     def get_iou(self, pi, po, il, pn): return _t(O.get_iou(_np(pi), _np(po), _np(il), _np(pn)))
     def get_mask_iou_on_cluster(self, pi, po, il, pn): return _t(O.get_mask_iou_on_cluster(_np(pi), _np(po), _np(il), _np(pn)))
     def get_mask_iou_on_pred(self, pi, po, il, pn, sg): return _t(O.get_mask_iou_on_pred(_np(pi), _np(po), _np(il), _np(pn), _np(sg)))
