@@ -1,12 +1,12 @@
 """Tiny Hydra-shaped config loader (the reference uses Hydra/OmegaConf, which are not in this image):
 `defaults` lists, group selection (`model=hais`), dotted `key=value` overrides, `${a.b}` interpolation and
-attribute access -- enough for the reference's config tree (config/config.yaml, config/{data,model}/*.yaml)."""
-import os
+attribute access over the defaults in config/defaults.py."""
+import copy
 import re
 
 import yaml
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+from .defaults import GROUPS, TOP
 
 
 class Cfg(dict):
@@ -38,8 +38,7 @@ def _merge(a, b):
 
 
 def _load_group(group, name):
-    with open(os.path.join(_HERE, group, name + ".yaml")) as f:
-        d = yaml.safe_load(f) or {}
+    d = copy.deepcopy(GROUPS[group][name])
     out = {}
     for base in d.pop("defaults", []):
         _merge(out, _load_group(group, base))
@@ -77,8 +76,7 @@ def _resolve(root, node):
 
 def load_config(overrides=()):
     """load_config(["model=hais", "model.network.m=16", "data.batch_size=2"])"""
-    with open(os.path.join(_HERE, "config.yaml")) as f:
-        top = yaml.safe_load(f)
+    top = copy.deepcopy(TOP)
     groups = {}
     for item in top.pop("defaults", []):
         (g, n), = item.items()

@@ -1,4 +1,6 @@
-"""Sparse U-Net backbone + the two per-point heads (reference minsu3d/model/module/backbone.py:8-43)."""
+"""Networks assembled from the U-Net blocks: the `Backbone` (sparse U-Net + semantic / offset heads over points;
+reference minsu3d/model/module/backbone.py:8-43) and the `TinyUnet` that refines voxelised proposals (reference
+minsu3d/model/module/tiny_unet.py:7-19).  Sub-module names follow the reference so checkpoints keep their keys."""
 import torch.nn as nn
 
 from ... import MinkowskiEngine as ME
@@ -38,3 +40,16 @@ class Backbone(nn.Module):
         return {"point_features": point_features,
                 "semantic_scores": self.semantic_branch(point_features),
                 "point_offsets": self.offset_branch(point_features)}
+
+
+class TinyUnet(nn.Module):
+    """two-level U-Net (channel -> 2*channel -> channel) + BN + ReLU, run once on all proposals of a batch"""
+
+    def __init__(self, channel):
+        super().__init__()
+        levels = [channel, 2 * channel]
+        self.unet = nn.Sequential(UBlock(levels, ME.MinkowskiBatchNorm, 2, ResidualBlock),
+                                  ME.MinkowskiBatchNorm(channel), ME.MinkowskiReLU(inplace=True))
+
+    def forward(self, proposals_voxel_feats):
+        return self.unet(proposals_voxel_feats)
