@@ -36,8 +36,8 @@ const char *ms3d_version(void);
 size_t ms3d_ballquery_workspace_bytes(int n);
 int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz, const uint8_t *batch_idxs,
                            const int *batch_offsets, int n_scenes, int max_scene_points, int *idx,
-                           int *start_len, int *n_active /*[host]*/, void *workspace, size_t workspace_bytes,
-                           ms3d_stream_t stream);
+                           int *start_len, int *n_active /*[host]*/, int *capped /*[host] or NULL: 1 if any list hit 1000*/,
+                           void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
 
 /* ---- BFS clustering: replaces pg_bfs_cluster / sg_bfs_cluster, bfs_cluster/bfs_cluster.h:18-19
  * (host C++ bfs_cluster.cpp:28-187).  Runs on the DEVICE (the reference copies the ball-query
@@ -46,18 +46,21 @@ int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz
  * the 1000-neighbour cap bites.  cluster_idxs has capacity [N,2], cluster_offsets [N+1];
  * counts[0] = nCluster, counts[1] = sumNPoint are returned to the [host]. */
 size_t ms3d_bfs_workspace_bytes(int N);
+/* capped_hint: what ms3d_ballquery_batch_p reported for this graph (0 = no list reached 1000 -> symmetric graph,
+ * 1 = some did, -1 = unknown: decided on the device at the price of one host sync) */
 int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, long n_edges /* = nActive */,
-                        const int *start_len, int N, int threshold, int *cluster_idxs, int *cluster_offsets, int *counts /*[host,2]*/,
+                        const int *start_len, int N, int threshold, int capped_hint, int *cluster_idxs, int *cluster_offsets, int *counts /*[host,2]*/,
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
 int ms3d_sg_bfs_cluster(const float *class_numpoint_mean /*[host]*/, const int *ball_query_idxs, long n_edges,
-                        const int *start_len, int N, float threshold, int class_id, int *cluster_idxs,
+                        const int *start_len, int N, float threshold, int capped_hint, int class_id, int *cluster_idxs,
                         int *cluster_offsets, int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes,
                         ms3d_stream_t stream);
 
 /* all SoftGroup classes in one call: group_of_point u8[N] (class*B + scene, non-decreasing), thr_per_group f32[G]
  * (device); output clusters are class-major = the reference's per-class concatenation (model/softgroup.py:43-83) */
 int ms3d_sg_bfs_cluster_batched(const uint8_t *group_of_point, const float *thr_per_group, const int *ball_query_idxs,
-                                long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets,
+                                long n_edges, const int *start_len, int N, int capped_hint, int *cluster_idxs,
+                                int *cluster_offsets,
                                 int *counts /*[host,2]*/, void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
 
 /* ---- HAIS: replaces hierarchical_aggregation, hierarchical_aggregation/hierarchical_aggregation.h:14-28

@@ -33,6 +33,9 @@ def _i32(t):
     return t if t.dtype == torch.int32 else t.to(torch.int32)
 
 
+_HINT = object()   # placeholder in a C argument list: replaced by the capped/symmetric hint of the graph
+
+
 class _Workspace:
     """grow-only device scratch, one per purpose (avoids hipMalloc on the hot path)"""
 
@@ -73,25 +76,36 @@ class HipBackend:
         if n == 0:
             return torch.zeros(0, dtype=torch.int32, device=dev), start_len
         if max_scene_points <= 0:
-            # tight per-scene bound -> smaller LDS bitmap, more waves per CU (the call syncs for nActive anyway)
-            max_scene_points = int((batch_offsets[1:] - batch_offsets[:-1]).max().item())
+            # tight per-scene bound -> smaller LDS bitmap, more waves per CU; the models query the same scene layout
+            # twice (shifted / original coordinates), so the value is remembered per offsets tensor
+            key = (batch_offsets.data_ptr(), batch_offsets._version, batch_offsets.numel())
+            cached = getattr(self, "_max_scene_cache", None)
+            if cached is None or cached[0] != key:
+                cached = (key, int((batch_offsets[1:] - batch_offsets[:-1]).max().item()))
+                self._max_scene_cache = cached
+            max_scene_points = cached[1]
         ws_bytes = self.lib.ms3d_ballquery_workspace_bytes(n)
         ws = self.ws.get("bq", ws_bytes, dev)
-        n_active = C.c_int(0)
+        n_active, capped = C.c_int(0), C.c_int(0)
         while True:
             idx = torch.empty(n * meanActive, dtype=torch.int32, device=dev)
             rc = self.lib.ms3d_ballquery_batch_p(
                 n, int(meanActive), C.c_float(radius), _lib.ptr(coords), _lib.ptr(batch_idxs),
                 _lib.ptr(batch_offsets), int(batch_offsets.numel() - 1), int(max_scene_points), _lib.ptr(idx),
-                _lib.ptr(start_len), C.byref(n_active), _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle())
+                _lib.ptr(start_len), C.byref(n_active), C.byref(capped), _lib.ptr(ws), C.c_size_t(ws.numel()),
+                _lib.stream_handle())
             _lib.check(rc, "ms3d_ballquery_batch_p")
             if n_active.value <= n * meanActive:
                 break
             meanActive = int(n_active.value // n + 1)
+        # remembered for the clustering call that consumes this graph: "no list reached the 1000 cap" means the graph
+        # is symmetric, which lets the BFS skip a device->host check
+        start_len._ms3d_capped = int(capped.value)
         return idx[:n_active.value], start_len
 
     # ------------------------------------------------------------------ BFS
     def _bfs(self, fn_name, args_head, ball_idx, start_len, args_tail):
+        hint = int(getattr(start_len, "_ms3d_capped", -1))   # set by ballquery_batch_p on the tensor it returned
         ball_idx = self._dev(ball_idx); start_len = self._dev(start_len)
         N = start_len.size(0)
         dev = start_len.device
@@ -100,6 +114,7 @@ class HipBackend:
         ws_bytes = self.lib.ms3d_bfs_workspace_bytes(N)
         ws = self.ws.get("bfs", ws_bytes, dev)
         counts = (C.c_int * 2)(0, 0)
+        args_tail = tuple(hint if a is _HINT else a for a in args_tail)
         rc = getattr(self.lib, fn_name)(*args_head, _lib.ptr(ball_idx), C.c_long(ball_idx.numel()), _lib.ptr(start_len), N,
                                         *args_tail,
                                         _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), counts, _lib.ptr(ws),
@@ -110,17 +125,17 @@ class HipBackend:
     def pg_bfs_cluster(self, semantic_label, ball_query_idxs, start_len, threshold):
         sem = self._dev(semantic_label)
         assert sem.dtype == torch.int16
-        return self._bfs("ms3d_pg_bfs_cluster", (_lib.ptr(sem),), ball_query_idxs, start_len, (int(threshold),))
+        return self._bfs("ms3d_pg_bfs_cluster", (_lib.ptr(sem),), ball_query_idxs, start_len, (int(threshold), _HINT))
 
     def sg_bfs_cluster(self, class_numpoint_mean, ball_query_idxs, start_len, threshold, class_id):
         mean = (C.c_float * len(class_numpoint_mean))(*[float(x) for x in class_numpoint_mean])
         return self._bfs("ms3d_sg_bfs_cluster", (mean,), ball_query_idxs, start_len,
-                         (C.c_float(threshold), int(class_id)))
+                         (C.c_float(threshold), _HINT, int(class_id)))
 
     def sg_bfs_cluster_batched(self, group_of_point, thr_per_group, ball_query_idxs, start_len):
         g = self._dev(group_of_point); t = self._dev(thr_per_group)
         assert g.dtype == torch.uint8 and t.dtype == torch.float32
-        return self._bfs("ms3d_sg_bfs_cluster_batched", (_lib.ptr(g), _lib.ptr(t)), ball_query_idxs, start_len, ())
+        return self._bfs("ms3d_sg_bfs_cluster_batched", (_lib.ptr(g), _lib.ptr(t)), ball_query_idxs, start_len, (_HINT,))
 
     def hierarchical_aggregation(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
                                  point_num_avg, radius_avg, ignored_label=-1):

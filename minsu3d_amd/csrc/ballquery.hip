@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
             if (l == 0) {
                 start_len[i * 2 + 0] = my_start;
                 start_len[i * 2 + 1] = my_len;
+                if (my_len >= BQ_CAP && (flags[0] & 2) == 0) atomicOr(flags, 2);  // a list reached the cap: graph may be directed
             }
         }
         int nhits = 0;
@@ -304,11 +305,13 @@ size_t ms3d_ballquery_workspace_bytes(int n)
 
 int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz, const uint8_t *batch_idxs,
                            const int *batch_offsets, int n_scenes, int max_scene_points, int *idx, int *start_len,
-                           int *n_active, void *workspace, size_t workspace_bytes, ms3d_stream_t stream_)
+                           int *n_active, int *capped_out, void *workspace, size_t workspace_bytes,
+                           ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)n_scenes;
     *n_active = 0;
+    if (capped_out) *capped_out = 0;
     if (n <= 0) return 0;
     BqWorkspace w;
     if (carve(w, n, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
@@ -365,6 +368,7 @@ int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz
     MS3D_CHECK(hipStreamSynchronize(stream));
     if (host[1] & 1) return MS3D_E_UNSUPPORTED;
     *n_active = host[0];
+    if (capped_out) *capped_out = (host[1] & 2) ? 1 : 0;
     return 0;
 }
 

@@ -311,7 +311,7 @@ __global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int nwork = counters[0];
     if (w == 0) counters[6] = nwork;
-    if (w >= nwork) return;
+    if (w >= nwork) return;  // launched for the upper bound N
     const int r = worklist[w];
     F0[w] = r;
     comp_base[r] = atomicAdd(&counters[2], comp_size[r]);
@@ -485,7 +485,8 @@ int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, 
                           void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 namespace {
-int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, const int *start_len, int N, int *cluster_idxs,
+int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, long n_edges, const int *start_len, int N,
+            int *cluster_idxs,
             int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     counts[0] = counts[1] = 0;
@@ -506,49 +507,48 @@ int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, cons
     MS3D_LAUNCH_CHECK();
     // Dense symmetric graphs (shifted coordinates: hundreds of neighbours per point, a handful of BFS levels)
     // are expanded by the whole chip level by level; sparse or capped (directed) graphs by the replay kernel.
-    bool replay = true;
+    // When the ball query already told us that no list was capped (capped_hint == 0) nothing has to be read back
+    // before the expansion; the frontier size is checked together with the final counts.
+    bool replay = true, dense = false;
+    const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
+    int level = 0;
+    auto run_levels = [&](int nlev) -> int {
+        const int grid = 256 * 8;
+        for (int it = 0; it < nlev; it++, level++) {
+            int *Fc = (level & 1) ? w.Fb : w.Fa, *Fn = (level & 1) ? w.Fa : w.Fb;
+            int *nFc = w.counters + 6 + (level & 1), *nFn = w.counters + 6 + ((level + 1) & 1);
+            glob_claim_kernel<<<grid, 256, 0, stream>>>(thr, sem, ball_idx, start_len, w.root, Fc, nFc, w.comp_base, w.done,
+                                                       w.seg_start, w.claim, w.scratch_node, w.scratch_seed);
+            MS3D_LAUNCH_CHECK();
+            glob_update_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.done, w.seg_start, w.seg_cnt);
+            MS3D_LAUNCH_CHECK();
+            glob_win_kernel<false><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim, w.cnt, nullptr,
+                                                            nullptr, nullptr, nullptr);
+            MS3D_LAUNCH_CHECK();
+            int rc2 = ms3d_exclusive_scan_i32(w.cnt, w.cnt, N, nFn, w.scan_ws, stream);
+            if (rc2) return rc2;
+            glob_win_kernel<true><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim, nullptr, w.cnt,
+                                                           Fn, w.seg_start, w.seg_cnt);
+            MS3D_LAUNCH_CHECK();
+        }
+        return 0;
+    };
     if (n_edges >= (long)N * 24) {
-        int h[8];
-        MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
-        MS3D_CHECK(hipStreamSynchronize(stream));
-        const int nwork = h[0];
-        if (h[5] == 0) {
+        int capped = capped_hint;
+        if (capped < 0) {
+            int h[8];
+            MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+            MS3D_CHECK(hipStreamSynchronize(stream));
+            capped = h[5];
+        }
+        if (capped == 0) {
             replay = false;
-            if (nwork > 0) {
-                glob_init_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa,
-                                                                            w.comp_base, w.done, w.seg_start, w.seg_cnt,
-                                                                            w.claim);
-                MS3D_LAUNCH_CHECK();
-                const int grid = 256 * 8;
-                int level = 0;
-                for (;;) {
-                    for (int it = 0; it < 16; it++, level++) {
-                        int *Fc = (level & 1) ? w.Fb : w.Fa, *Fn = (level & 1) ? w.Fa : w.Fb;
-                        int *nFc = w.counters + 6 + (level & 1), *nFn = w.counters + 6 + ((level + 1) & 1);
-                        glob_claim_kernel<<<grid, 256, 0, stream>>>(thr, sem, ball_idx, start_len, w.root, Fc, nFc,
-                                                                   w.comp_base, w.done, w.seg_start, w.claim,
-                                                                   w.scratch_node, w.scratch_seed);
-                        MS3D_LAUNCH_CHECK();
-                        glob_update_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.counters, w.done,
-                                                                                      w.seg_start, w.seg_cnt);
-                        MS3D_LAUNCH_CHECK();
-                        glob_win_kernel<false><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim,
-                                                                        w.cnt, nullptr, nullptr, nullptr, nullptr);
-                        MS3D_LAUNCH_CHECK();
-                        int rc2 = ms3d_exclusive_scan_i32(w.cnt, w.cnt, N, nFn, w.scan_ws, stream);
-                        if (rc2) return rc2;
-                        glob_win_kernel<true><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim,
-                                                                       nullptr, w.cnt, Fn, w.seg_start, w.seg_cnt);
-                        MS3D_LAUNCH_CHECK();
-                    }
-                    MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
-                    MS3D_CHECK(hipStreamSynchronize(stream));
-                    if (h[6 + (level & 1)] == 0) break;  // frontier empty: every component is exhausted
-                }
-                glob_finish_kernel<<<ms3d_divup(nwork, 256), 256, 0, stream>>>(w.worklist, w.counters, w.comp_size,
-                                                                              w.comp_base, w.cl_size, w.cl_start);
-                MS3D_LAUNCH_CHECK();
-            }
+            dense = true;
+            glob_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done,
+                                                         w.seg_start, w.seg_cnt, w.claim);
+            MS3D_LAUNCH_CHECK();
+            int rc2 = run_levels(16);
+            if (rc2) return rc2;
         }
     }
     if (replay) {
@@ -557,6 +557,14 @@ int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, cons
                                                               w.scratch_seed, w.cl_size, w.cl_start);
         MS3D_LAUNCH_CHECK();
     }
+    int host[8];
+    for (;;) {
+        if (dense) {
+            // cnt / Fa / Fb alias the assembly buffers: the (idempotent) assembly below runs after the expansion
+            glob_finish_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.comp_size, w.comp_base, w.cl_size,
+                                                           w.cl_start);
+            MS3D_LAUNCH_CHECK();
+        }
     bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
     MS3D_LAUNCH_CHECK();
     int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
@@ -566,9 +574,25 @@ int bfs_run(Thr thr, const int16_t *sem, const int *ball_idx, long n_edges, cons
     bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
                                            w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
     MS3D_LAUNCH_CHECK();
-    int host[8];
-    MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
-    MS3D_CHECK(hipStreamSynchronize(stream));
+        MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipStreamSynchronize(stream));
+        if (!dense || host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
+        // rare: more than `level` BFS levels; the frontier buffers alias the assembly scratch, so the expansion state
+        // cannot be resumed -> finish with the replay kernel from a clean state
+        dense = false;
+        bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.counters);
+        MS3D_LAUNCH_CHECK();
+        bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
+        MS3D_LAUNCH_CHECK();
+        bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
+        MS3D_LAUNCH_CHECK();
+        bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        MS3D_LAUNCH_CHECK();
+    }
     counts[0] = host[3];
     counts[1] = host[4];
     return 0;
@@ -581,7 +605,7 @@ int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, 
                           void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     Thr thr{mode, thr_i, thr_f, nullptr, nullptr};
-    return bfs_run(thr, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+    return bfs_run(thr, -1, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, stream);
 }
 
@@ -594,21 +618,21 @@ size_t ms3d_bfs_workspace_bytes(int N)
 }
 
 int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, long n_edges, const int *start_len,
-                        int N, int threshold, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
+                        int N, int threshold, int capped_hint, int *cluster_idxs, int *cluster_offsets, int *counts, void *workspace,
                         size_t workspace_bytes, ms3d_stream_t stream)
 {
     Thr thr{0, threshold, 0.f, nullptr, nullptr};
-    return bfs_run(thr, semantic_label, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts,
+    return bfs_run(thr, capped_hint, semantic_label, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts,
                    workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_idxs, long n_edges,
-                        const int *start_len, int N, float threshold, int class_id, int *cluster_idxs, int *cluster_offsets, int *counts,
+                        const int *start_len, int N, float threshold, int capped_hint, int class_id, int *cluster_idxs, int *cluster_offsets, int *counts,
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
 {
     const float m = class_numpoint_mean[class_id];  // bfs_cluster.cpp:113-120
     Thr thr{1, 0, (m == -1.f) ? threshold : threshold * m, nullptr, nullptr};
-    return bfs_run(thr, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+    return bfs_run(thr, capped_hint, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, (hipStream_t)stream);
 }
 
@@ -618,11 +642,12 @@ int ms3d_sg_bfs_cluster(const float *class_numpoint_mean, const int *ball_query_
 // (threshold or threshold*class_numpoint_mean[class], bfs_cluster.cpp:113-120).  Clusters come out by ascending seed,
 // i.e. class-major -- exactly the order in which the reference concatenates its per-class results.
 int ms3d_sg_bfs_cluster_batched(const uint8_t *group_of_point, const float *thr_per_group, const int *ball_query_idxs,
-                                long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets,
-                                int *counts, void *workspace, size_t workspace_bytes, ms3d_stream_t stream)
+                                long n_edges, const int *start_len, int N, int capped_hint, int *cluster_idxs,
+                                int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes,
+                                ms3d_stream_t stream)
 {
     Thr thr{2, 0, 0.f, group_of_point, thr_per_group};
-    return bfs_run(thr, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+    return bfs_run(thr, capped_hint, nullptr, ball_query_idxs, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, (hipStream_t)stream);
 }
 

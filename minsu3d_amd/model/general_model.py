@@ -68,6 +68,14 @@ class GeneralModel(nn.Module):
             g["lr"] = lr
 
 
+def scene_offsets(batch_idxs, n_scenes):
+    """i32 [n_scenes+1] start of every scene in a scene-grouped point list -- the reference's
+    cumsum(bincount(batch_idxs + 1)) (pointgroup.py:37) without bincount's device->host max() round trip"""
+    counts = torch.zeros(n_scenes + 1, dtype=torch.int64, device=batch_idxs.device)
+    counts.scatter_add_(0, batch_idxs.long() + 1, torch.ones_like(batch_idxs, dtype=torch.int64))
+    return torch.cumsum(counts, dim=0).int()
+
+
 def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None):
     """Per-proposal recentre / rescale into a `spatial_shape` cube, random placement, integer cast, dedupe into
     voxels (reference general_model.py:152-193).  `rand` = the two U(0,1)^3 draws shared by all proposals

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ..common_ops.functions import common_ops, hais_ops
-from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores
+from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
 
 
@@ -35,7 +35,7 @@ class HAIS(GeneralModel):
             fg &= sem_pred != (cls - 1)
         object_idxs = torch.nonzero(fg).view(-1)
         batch_idxs = data_dict["vert_batch_ids"][object_idxs]
-        batch_offsets = torch.cumsum(torch.bincount(batch_idxs + 1), dim=0).int()
+        batch_offsets = scene_offsets(batch_idxs, len(data_dict["scan_ids"]))
         shifted = (data_dict["point_xyz"][object_idxs] + offsets[object_idxs]).detach().contiguous()
         idx, start_len = common_ops.ballquery_batch_p(shifted, batch_idxs, batch_offsets, net.point_aggr_radius,
                                                       net.cluster_shift_meanActive)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
 from ..common_ops.functions import common_ops, pointgroup_ops
-from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores
+from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
 
 
@@ -47,7 +47,7 @@ class PointGroup(GeneralModel):
             fg &= sem_pred != (cls - 1)
         object_idxs = torch.nonzero(fg).view(-1)
         batch_idxs = data_dict["vert_batch_ids"][object_idxs]
-        batch_offsets = torch.cumsum(torch.bincount(batch_idxs + 1), dim=0).int()
+        batch_offsets = scene_offsets(batch_idxs, len(data_dict["scan_ids"]))
         xyz = data_dict["point_xyz"][object_idxs]
         shifted = (xyz + grouping_offsets[object_idxs]).detach().contiguous()
         sem_fg = sem_pred[object_idxs].contiguous()

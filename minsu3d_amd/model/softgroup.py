@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ..common_ops.functions import common_ops, softgroup_ops
-from .general_model import GeneralModel, clusters_voxelization
+from .general_model import GeneralModel, clusters_voxelization, scene_offsets
 from .module import TinyUnet
 
 
@@ -79,7 +79,7 @@ class SoftGroup(GeneralModel):
         if pt.numel() == 0:
             return torch.zeros((0, 2), dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
         group = (cls_id * B + data_dict["vert_batch_ids"][pt].long()).to(torch.uint8)
-        group_offsets = torch.cumsum(torch.bincount(group.long() + 1, minlength=C_ * B + 1), dim=0).int()
+        group_offsets = scene_offsets(group, C_ * B)
         shifted = (data_dict["point_xyz"][pt] + offsets[pt]).detach().contiguous()
         idx, start_len = common_ops.ballquery_batch_p(shifted, group, group_offsets, net.grouping_cfg.radius,
                                                       net.grouping_cfg.mean_active)

@@ -76,7 +76,8 @@ def test_get_segmented_scores_and_offset_loss():
     pred = torch.tensor([[1.0, 0, 0], [0, 2.0, 0], [5.0, 5, 5]]); gt = torch.tensor([[1.0, 0, 0], [0, -1.0, 0], [0.0, 0, 0]])
     n, d = PTOffsetLoss()(pred, gt, torch.tensor([True, True, False]))
     assert torch.isclose(n, torch.tensor(1.5)) and torch.isclose(d, torch.tensor(0.0))
-    assert PTOffsetLoss()(pred, gt, torch.tensor([False, False, False])) == (0, 0)
+    z = PTOffsetLoss()(pred, gt, torch.tensor([False, False, False]))
+    assert float(z[0]) == 0.0 and float(z[1]) == 0.0
 
 
 def test_clusters_voxelization_semantics(cpu_backend):
