@@ -78,11 +78,11 @@ class HipBackend:
         if max_scene_points <= 0:
             # tight per-scene bound -> smaller LDS bitmap, more waves per CU; the models query the same scene layout
             # twice (shifted / original coordinates), so the value is remembered per offsets tensor
-            key = (batch_offsets.data_ptr(), batch_offsets._version, batch_offsets.numel())
-            cached = getattr(self, "_max_scene_cache", None)
-            if cached is None or cached[0] != key:
-                cached = (key, int((batch_offsets[1:] - batch_offsets[:-1]).max().item()))
-                self._max_scene_cache = cached
+            # (kept as an attribute of the tensor object: addresses are recycled by the allocator, objects are not)
+            cached = getattr(batch_offsets, "_ms3d_max_scene", None)
+            if cached is None or cached[0] != batch_offsets._version:
+                cached = (batch_offsets._version, int((batch_offsets[1:] - batch_offsets[:-1]).max().item()))
+                batch_offsets._ms3d_max_scene = cached
             max_scene_points = cached[1]
         ws_bytes = self.lib.ms3d_ballquery_workspace_bytes(n)
         ws = self.ws.get("bq", ws_bytes, dev)

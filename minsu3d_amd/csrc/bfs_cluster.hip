@@ -23,6 +23,8 @@
 //
 // All state lives in a caller-provided workspace; the only host traffic is the final 8-byte
 // (nCluster, sumNPoint) read the caller needs to size its tensors.
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 #include "scan.h"
 #include "../../include/minsu3d_hip.h"
@@ -77,7 +79,7 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b)
 }
 
 __global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited, int *claim, int *cl_size,
-                                int *counters)
+                                int *scratch_seed, int *counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
@@ -86,6 +88,7 @@ __global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited
         visited[i] = 0;
         claim[i] = INT_BIG;
         cl_size[i] = 0;
+        scratch_seed[i] = -1;  // "slot not written": the assembly may run before an incomplete expansion is detected
     }
     if (i < 8) counters[i] = 0;
 }
@@ -442,7 +445,7 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
     const int used = counters[2];
     if (t < used) {
         const int seed = scratch_seed[t];
-        if (keep_size[seed] > 0) {
+        if (seed >= 0 && keep_size[seed] > 0) {
             const int pos = out_off[seed] + (t - cl_start[seed]);
             cluster_idxs[pos * 2 + 0] = cid[seed];
             cluster_idxs[pos * 2 + 1] = scratch_node[t];
@@ -497,7 +500,8 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     BfsWorkspace w;
     if (carve(w, N, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
     const int nb = ms3d_divup(N, 256);
-    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.counters);
+    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
+                                           w.counters);
     MS3D_LAUNCH_CHECK();
     bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
     MS3D_LAUNCH_CHECK();
@@ -509,6 +513,13 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     // are expanded by the whole chip level by level; sparse or capped (directed) graphs by the replay kernel.
     // When the ball query already told us that no list was capped (capped_hint == 0) nothing has to be read back
     // before the expansion; the frontier size is checked together with the final counts.
+    static const bool dbg = getenv("MS3D_DEBUG") != nullptr;
+#define DBG(tag)                                                                                             \
+    if (dbg) {                                                                                               \
+        hipError_t e_ = hipStreamSynchronize(stream);                                                        \
+        fprintf(stderr, "[bfs] %s N=%d edges=%ld mode=%d hint=%d err=%d\n", tag, N, n_edges, thr.mode, capped_hint, (int)e_); \
+    }
+    DBG("after select");
     bool replay = true, dense = false;
     const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
     int level = 0;
@@ -547,8 +558,10 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
             glob_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done,
                                                          w.seg_start, w.seg_cnt, w.claim);
             MS3D_LAUNCH_CHECK();
+            DBG("after glob_init");
             int rc2 = run_levels(16);
             if (rc2) return rc2;
+            DBG("after levels");
         }
     }
     if (replay) {
@@ -574,13 +587,16 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
                                            w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
     MS3D_LAUNCH_CHECK();
+        DBG("after emit");
         MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
         MS3D_CHECK(hipStreamSynchronize(stream));
+        if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], level);
         if (!dense || host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
         // rare: more than `level` BFS levels; the frontier buffers alias the assembly scratch, so the expansion state
         // cannot be resumed -> finish with the replay kernel from a clean state
         dense = false;
-        bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.counters);
+        bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
+                                           w.counters);
         MS3D_LAUNCH_CHECK();
         bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
         MS3D_LAUNCH_CHECK();

@@ -316,3 +316,23 @@ def test_hais_set_aggregation_vs_reference_on_gpu(be, oracle):
     assert np.array_equal(a[:, 0], ri[:, 0])
     for c in range(o.size - 1):
         assert np.array_equal(np.sort(a[o[c]:o[c + 1], 1]), np.sort(ri[o[c]:o[c + 1], 1]))
+
+
+def test_bfs_dense_graph_with_many_levels(be, oracle):
+    """dense (hundreds of neighbours) but ~100 BFS levels deep: the chip-wide expansion gives up after its level budget,
+    the assembly has already run speculatively, and the replay kernel must produce the exact result"""
+    rng = np.random.default_rng(31)
+    n = 24000
+    t = rng.random(n) * 3.0
+    xyz = np.stack([t, rng.standard_normal(n) * 0.004, rng.standard_normal(n) * 0.004], 1).astype(np.float32)
+    xyz[n // 2:, 1] += 1.0                               # two tubes -> two clusters
+    b = np.zeros(n, np.uint8); bo = np.array([0, n], np.int32)
+    sem = np.full(n, 3, np.int16)
+    idx_d, sl_d = be.ballquery_batch_p(dev(xyz), dev(b), dev(bo), 0.03, 300)
+    idx, sl = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+    assert np.array_equal(idx_d.cpu().numpy(), idx) and idx.size > 24 * n and sl[:, 1].max() < 1000
+    want = oracle.pg_bfs_cluster(sem, idx, sl, 50)
+    for graph in ((idx_d, sl_d), (dev(idx), dev(sl))):   # with and without the "not capped" hint of the ball query
+        a, o = be.pg_bfs_cluster(dev(sem), graph[0], graph[1], 50)
+        assert np.array_equal(o.cpu().numpy(), want[1]) and o.numel() - 1 == 2
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))

@@ -184,3 +184,41 @@ def test_mini_unet_hip_vs_torch(be):
             assert rel_err(got[n], p.grad) < 2e-3, n
     finally:
         backend.set_backend(prev)
+
+
+def test_mini_unet_eval_mode_backward_hip_vs_torch(be):
+    """BatchNorm in eval mode (running statistics): forward and input/parameter gradients through the fused layers"""
+    import minsu3d_amd.MinkowskiEngine as ME
+    from minsu3d_amd import backend
+    prev = backend.set_backend(be)
+    try:
+        rng = np.random.default_rng(6)
+        c = surface_coords(rng, 1, 6000, extent=30)
+        feats = rng.standard_normal((c.shape[0], 6)).astype(np.float32)
+        net = _unet_like(ME).cuda()
+        run_me_chain(ME, net, dev(feats), dev(c))                       # one training pass fills the running stats
+        net.eval()
+        ft = dev(feats).requires_grad_(True)
+        out = run_me_chain(ME, net, ft, dev(c))
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        got = {n: p.grad.clone() for n, p in net.named_parameters()}
+        gx = ft.grad.clone()
+        net.zero_grad(); ft.grad = None
+        cm = ME.CoordinateManager(dev(c))
+        import torch.nn.functional as F
+        bn = lambda m, x: torch.relu(F.batch_norm(x, m.bn.running_mean, m.bn.running_var, m.bn.weight, m.bn.bias, False))
+        h = ref_conv(ft, net["conv0"].kernel, cm.k3(1))
+        h2 = ref_conv(bn(net["bn1"], h), net["conv1"].kernel, cm.k3(1)) + h
+        down, up = cm.k2(1)
+        d = ref_conv(bn(net["bn2"], h2), net["down"].kernel, down)
+        d = ref_conv(bn(net["bn3"], d), net["mid"].kernel, cm.k3(2))
+        u = ref_conv(bn(net["bn4"], d), net["up"].kernel, up)
+        ref = bn(net["bn5"], torch.cat([h2, u], 1) @ net["lin"].kernel)
+        assert rel_err(out, ref) < 5e-4
+        ref.backward(gout)
+        assert rel_err(gx, ft.grad) < 2e-3
+        for n, p in net.named_parameters():
+            assert rel_err(got[n], p.grad) < 2e-3, n
+    finally:
+        backend.set_backend(prev)
