@@ -518,19 +518,19 @@ int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 // ------------------------------------------------------------------ BN helper kernels
 // column sums over a [nparts][2][C] partial buffer -> mean / invstd / scale / shift (+ running stats).
 // One block per 16 channels; 16 part-lanes per channel sum in double, combined in a fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_stats_kernel(const float *__restrict__ partial, int nparts, int C, long V,
+__global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(const float *__restrict__ partial, int nparts, int C, long V,
                                                                 float eps, float momentum, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, float *running_mean,
                                                                 float *running_var, float *__restrict__ mean_out,
                                                                 float *__restrict__ invstd_out, float *__restrict__ scale_out,
                                                                 float *__restrict__ shift_out)
 {
-    __shared__ double s_1[16][17], s_2[16][17];
-    const int cl = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    __shared__ double s_1[64][17], s_2[64][17];
+    const int cl = threadIdx.x & 15, lp = threadIdx.x >> 4;  // 16 columns x 64 part lanes
     const int c = blockIdx.x * 16 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < C)
-        for (int p = lp; p < nparts; p += 16) {
+        for (int p = lp; p < nparts; p += 64) {
             a1 += (double)partial[((size_t)p * 2 + 0) * C + c];
             a2 += (double)partial[((size_t)p * 2 + 1) * C + c];
         }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void bn_finalize_stats_kernel(const float *__r
     __syncthreads();
     if (threadIdx.x >= 16 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 64; i++) {  // fixed order -> deterministic
         s1 += s_1[i][cl];
         s2 += s_2[i][cl];
     }
@@ -660,19 +660,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
 }
 
 // out[t] = sum_p partial[p][t]: 16 columns x 16 part-lanes per block, fixed combination order
-__global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n,
-                                                             float *__restrict__ out)
+__global__ __launch_bounds__(1024) void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n,
+                                                              float *__restrict__ out)
 {
-    __shared__ double s_sum[16][17];
+    __shared__ double s_sum[64][17];
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane_p = threadIdx.x >> 4;
     double s = 0.0;
     if (col < n)
-        for (int p = lane_p; p < nparts; p += 16) s += (double)partial[(size_t)p * n + col];
+        for (int p = lane_p; p < nparts; p += 64) s += (double)partial[(size_t)p * n + col];
     s_sum[lane_p][threadIdx.x & 15] = s;
     __syncthreads();
     if (threadIdx.x < 16 && col < n) {
         double t = 0.0;
-        for (int i = 0; i < 16; i++) t += s_sum[i][threadIdx.x];
+        for (int i = 0; i < 64; i++) t += s_sum[i][threadIdx.x];
         out[col] = (float)t;
     }
 }
@@ -904,7 +904,7 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
     const int rows_per_block = (int)((V + nblk - 1) / nblk);
     bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
     MS3D_LAUNCH_CHECK();
-    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 256, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
+    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 1024, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
                                                                   running_mean, running_var, mean, invstd, scale, shift);
     MS3D_LAUNCH_CHECK();
     return 0;
@@ -915,7 +915,7 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
                      float *scale, float *shift, ms3d_stream_t stream)
 {
     if (V <= 0) return MS3D_E_UNSUPPORTED;
-    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 256, 0, (hipStream_t)stream>>>(partial, nparts, C, V, eps, momentum, gamma,
+    bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 1024, 0, (hipStream_t)stream>>>(partial, nparts, C, V, eps, momentum, gamma,
                                                                                 beta, running_mean, running_var, mean,
                                                                                 invstd, scale, shift);
     MS3D_LAUNCH_CHECK();
@@ -936,7 +936,7 @@ int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float
 // s1s2 [2][C] = column sums of a [nparts][2][C] partial buffer (fixed order -> deterministic)
 int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream)
 {
-    reduce_partial_kernel<<<ms3d_divup(n, 16), 256, 0, (hipStream_t)stream>>>(partial, nparts, n, out);
+    reduce_partial_kernel<<<ms3d_divup(n, 16), 1024, 0, (hipStream_t)stream>>>(partial, nparts, n, out);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
