@@ -143,6 +143,17 @@ int ms3d_downsample(const int *coords, int V, int tensor_stride, int *out_coords
 int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_down, int *nbr_up,
                  ms3d_stream_t stream);
 
+/* Pair list = tile-compacted form of an offset-major table, built once per table and shared by every convolution of
+ * the level (forward, backward-data, backward-weight).  Output rows are cut into tiles of 64; per tile and offset the
+ * valid (input row, output row) pairs are stored contiguously, padded to a multiple of 16 ("batch" = one MFMA group).
+ *   tile_start[tiles + 1]   first batch of each tile (exclusive scan; last = number of batches)
+ *   entries[2 * 16 * batches]  int2 per pair: (input row, (k << 8) | output row inside the tile); pad = (0, k<<8 | 64)
+ * capacity() is the worst case in entries (allocate 8 bytes each); only the used prefix is ever touched. */
+int ms3d_kmap_pairlist_tiles(int Vout);
+size_t ms3d_kmap_pairlist_capacity(int K, int Vout);
+int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
+                             size_t workspace_bytes /* >= ms3d_coord_workspace_bytes(1) */, ms3d_stream_t stream);
+
 /* spatial sort keys (batch | 45-bit Morton code): rows sorted by this key keep a voxel's 26 neighbours close in
  * memory, so the conv gathers of one XCD stay inside its own L2 slice */
 int ms3d_morton_keys(const int *coords, int V, long long *keys, ms3d_stream_t stream);
@@ -155,12 +166,16 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
 /* out[i,:] = sum_k act(in[nbr[k][i],:]) @ Weff[k] (+ residual); act = optional x*pre_scale+pre_shift (+ReLU).
  * With bn_x != NULL the epilogue is the backward of a fused BN+ReLU: out = dz = acc * [bn_x*bn_scale+bn_shift > 0]
  * and bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block sums of dz and dz*xhat. */
-int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout);
+int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist);
+/* 1 when the convolution kernels have a pair-list variant worth building the list for (full-resolution levels) */
+int ms3d_kmap_pairlist_wanted(int K, int Vout);
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
                         const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
-                        const float *bias /* [Cout] or NULL */, ms3d_stream_t stream);
+                        const float *bias /* [Cout] or NULL */,
+                        const int *pl_tile_start /* pair list of `nbr` (ms3d_kmap_pairlist_build) or NULL */,
+                        const int *pl_entries, ms3d_stream_t stream);
 /* out_stats != 0 (forward only): bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block
  * (sum, sum of squares) of the OUTPUT rows (after the residual add) -> feed ms3d_bn_finalize, no extra pass. */
 int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
@@ -181,6 +196,7 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout);
 int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
                               int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
                               const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
+                              const int *pl_tile_start /* pair list of nbr_fwd or NULL */, const int *pl_entries,
                               void *ev_start /* hipEvent_t or NULL */, void *ev_stop, ms3d_stream_t stream);
 /* HIP events for timing a launch on the stream it is issued on (recorded inside ms3d_spconv_layer_forward around
  * the convolution kernel only) */
@@ -190,7 +206,10 @@ float ms3d_event_elapsed_ms(void *start, void *stop);
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
-                               int need_dx, float *dx, float *dgb, float *dW, float *ws, ms3d_stream_t stream);
+                               int need_dx, float *dx, float *dgb, float *dW, float *ws,
+                               const int *pl_fwd_tile_start /* pair list of nbr_fwd or NULL */, const int *pl_fwd_entries,
+                               const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
+                               ms3d_stream_t stream);
 
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */
 int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,

@@ -381,6 +381,26 @@ class _HipEngine:
             self._ident[(n, device)] = t
         return t
 
+    def pairlist(self, nbr, K, vout):
+        """tile-compacted pair list of an offset-major table, built on first use and cached on the table tensor
+        (every convolution of a level shares it) -> (tile_start, entries) or (None, None) for small levels"""
+        pl = getattr(nbr, "_ms3d_pairlist", None)
+        if pl is None:
+            pl = (None, None)
+            if self.lib.ms3d_kmap_pairlist_wanted(int(K), int(vout)):
+                self.lib.ms3d_kmap_pairlist_capacity.restype = C.c_size_t
+                cap = self.lib.ms3d_kmap_pairlist_capacity(int(K), int(vout))
+                tiles = self.lib.ms3d_kmap_pairlist_tiles(int(vout))
+                tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=nbr.device)
+                entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
+                ws = self._cws(1, nbr.device)
+                _lib.check(self.lib.ms3d_kmap_pairlist_build(_lib.ptr(nbr), int(K), int(vout), _lib.ptr(tile_start),
+                                                             _lib.ptr(entries), _lib.ptr(ws), C.c_size_t(ws.numel()),
+                                                             _lib.stream_handle()), "ms3d_kmap_pairlist_build")
+                pl = (tile_start, entries)
+            nbr._ms3d_pairlist = pl
+        return pl
+
     def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None,
                      out_stats=False, bias=None):
         """out = sum_k act(x[nbr[k]]) @ Weff[k] (+ residual).  pre = (scale, shift) fuses BN(+ReLU) on the input.
@@ -391,8 +411,9 @@ class _HipEngine:
         ps, pb = (pre if pre is not None else (None, None))
         partial = None
         bnargs = [None] * 5
+        pl = self.pairlist(nbr, K, vout)
         if bn_bwd is not None or out_stats:
-            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout))
+            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), int(pl[0] is not None))
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
         if bn_bwd is not None:
             bnargs = [_f32(t) for t in bn_bwd]
@@ -400,7 +421,7 @@ class _HipEngine:
             _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
             _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
             *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), int(bool(out_stats)), _lib.ptr(_f32(bias)),
-            _lib.stream_handle()), "ms3d_spconv_forward")
+            _lib.ptr(pl[0]), _lib.ptr(pl[1]), _lib.stream_handle()), "ms3d_spconv_forward")
         if bn_bwd is None:
             return (out, partial) if out_stats else out
         s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)
@@ -420,8 +441,9 @@ class _HipEngine:
         wf_buf = torch.empty(nwf, dtype=torch.float32, device=dev)
         y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
         stats = None
+        pl = self.pairlist(nbr_fwd, K, vout)
         if want_stats:
-            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout))
+            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), int(pl[0] is not None))
             stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev)
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
@@ -430,8 +452,8 @@ class _HipEngine:
         _lib.check(self.lib.ms3d_spconv_layer_forward(
             _lib.ptr(x), _lib.ptr(self._dev(W3)), _lib.ptr(nbr_fwd), int(vout), int(K), int(cin), int(cout),
             int(bool(mirror_bwd)), _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
-            _lib.ptr(_f32(bias)), _lib.ptr(wf_buf), _lib.ptr(y), _lib.ptr(stats), ev0, ev1, _lib.stream_handle()),
-            "ms3d_spconv_layer_forward")
+            _lib.ptr(_f32(bias)), _lib.ptr(wf_buf), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(pl[0]), _lib.ptr(pl[1]),
+            ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")
         return y, stats, wf_buf
 
     def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx):
@@ -445,12 +467,15 @@ class _HipEngine:
         dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
         dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+        plf = self.pairlist(nbr_fwd, K, vout)
+        plb = self.pairlist(nbr_bwd, K, vin) if want_dx else (None, None)
         _lib.check(self.lib.ms3d_spconv_layer_backward(
             _lib.ptr(x), _lib.ptr(dy), _lib.ptr(wf_buf), _lib.ptr(nbr_fwd), _lib.ptr(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _lib.ptr(bn["scale"] if has_bn else None), _lib.ptr(bn["shift"] if has_bn else None),
             _lib.ptr(bn["mean"] if has_bn else None), _lib.ptr(bn["invstd"] if has_bn else None),
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _lib.ptr(dx),
-            _lib.ptr(dgb), _lib.ptr(dW), _lib.ptr(ws), _lib.stream_handle()), "ms3d_spconv_layer_backward")
+            _lib.ptr(dgb), _lib.ptr(dW), _lib.ptr(ws), _lib.ptr(plf[0]), _lib.ptr(plf[1]), _lib.ptr(plb[0]),
+            _lib.ptr(plb[1]), _lib.stream_handle()), "ms3d_spconv_layer_backward")
         return (dx if need_dx else None), dgb, dW
 
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):

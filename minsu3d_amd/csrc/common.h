@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define MS3D_WAVE 64
+#define MS3D_PL_ROWS 64  // output rows per tile of a pair list (ms3d_kmap_pairlist_build)
 
 // Every launcher returns 0 on success or a non-zero hipError_t; nothing ever calls exit().
 #define MS3D_CHECK(expr)                                   \

@@ -218,6 +218,54 @@ int rank_first(CoordWs &w, int n, int *count_host, hipStream_t stream)
     return 0;
 }
 
+// ------------------------------------------------------------------ pair lists (tile-compacted kernel maps)
+// One wave per tile of MS3D_PL_ROWS output rows.  Per offset the valid (input row, output row) pairs of the tile are
+// compacted with a ballot and padded to a multiple of 16 (a "batch": one MFMA group in the convolution kernels).
+// entry = (input row, (k << 8) | local output row); pad entries read input row 0 and carry local row MS3D_PL_ROWS.
+template <int KT>
+__global__ __launch_bounds__(256) void pairlist_count_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
+                                                             int *__restrict__ tile_nb)
+{
+    const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    if (tile > tiles) return;
+    if (tile == tiles) {  // slot for the grand total of the exclusive scan
+        if (lane_id() == 0) tile_nb[tiles] = 0;
+        return;
+    }
+    const int row = tile * MS3D_PL_ROWS + lane_id();
+    const bool ok = row < Vout;
+    int v[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) v[k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+    int nb = 0;
+#pragma unroll
+    for (int k = 0; k < KT; k++) nb += (__popcll(__ballot(v[k] >= 0)) + 15) >> 4;
+    if (lane_id() == 0) tile_nb[tile] = nb;
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
+                                                            const int *__restrict__ tile_start, int2 *__restrict__ entries)
+{
+    const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    if (tile >= tiles) return;
+    const int l = lane_id();
+    const int row = tile * MS3D_PL_ROWS + l;
+    const bool ok = row < Vout;
+    int v[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) v[k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+    size_t base = (size_t)tile_start[tile] * 16;
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        const unsigned long long m = __ballot(v[k] >= 0);
+        const int n = __popcll(m), n16 = (n + 15) & ~15;
+        if (v[k] >= 0) entries[base + ballot_rank(m)] = make_int2(v[k], (k << 8) | l);
+        if (l < n16 - n) entries[base + n + l] = make_int2(0, (k << 8) | MS3D_PL_ROWS);
+        base += n16;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,6 +343,38 @@ int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_do
     fill_minus1_kernel<<<ms3d_divup((long)Vf * 8, 256), 256, 0, stream>>>(nbr_up, (long)Vf * 8);
     MS3D_LAUNCH_CHECK();
     kmap_k2_kernel<<<ms3d_divup(Vf, 256), 256, 0, stream>>>(parent, koff, Vf, Vc, nbr_down, nbr_up);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_kmap_pairlist_tiles(int Vout) { return ms3d_divup(Vout, MS3D_PL_ROWS); }
+
+size_t ms3d_kmap_pairlist_capacity(int K, int Vout)
+{
+    // every (tile, offset) group pads by < 16 entries
+    return (size_t)K * ((size_t)Vout + 15 * (size_t)ms3d_divup(Vout, MS3D_PL_ROWS));
+}
+
+int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
+                             size_t workspace_bytes, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Vout <= 0) return 0;
+    if (K > 27) return MS3D_E_UNSUPPORTED;
+    if (workspace_bytes < ms3d_scan_workspace_bytes()) return MS3D_E_WORKSPACE;
+    const int tiles = ms3d_divup(Vout, MS3D_PL_ROWS);
+    const int grid = ms3d_divup((long)(tiles + 1) * 64, 256);
+    if (K <= 8)
+        pairlist_count_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+    else
+        pairlist_count_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+    MS3D_LAUNCH_CHECK();
+    int rc = ms3d_exclusive_scan_i32(tile_start, tile_start, tiles + 1, nullptr, workspace, stream);
+    if (rc) return rc;
+    if (K <= 8)
+        pairlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
+    else
+        pairlist_fill_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
     MS3D_LAUNCH_CHECK();
     return 0;
 }

@@ -56,6 +56,8 @@ struct ConvArgs {
     int G;      // offsets whose weights are LDS resident at once
     int ntiles;
     int pre_relu;
+    const int *pl_tile_start;  // pair list of the table (ms3d_kmap_pairlist_build) or null
+    const int *pl_entries;
 };
 
 // ------------------------------------------------------------------ weight permutation
@@ -379,6 +381,192 @@ int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool align
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         spconv_fwd_kernel<NBT, false><<<grid, threads, lds, stream>>>(p);
     }
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ pair-list forward / backward-data
+// Full-resolution levels are sparse: a voxel of a 2 cm ScanNet-like surface has ~3-9 of its 27 neighbours, so a
+// 16-row output tile that runs one MFMA group per offset whenever ANY of its rows has that neighbour keeps the matrix
+// pipe ~15 % useful, gathers 27 x 16 rows (most of them clamped dummies) and is bound by instruction issue.
+// With a pair list (ms3d_kmap_pairlist_build: per 64-row tile the valid pairs grouped by offset in 16-pair batches)
+// a wave owns a 64-row tile and per batch issues
+//     1 entry load, 1 row gather (16 B / lane), 1 weight-fragment read (ds_read_b128), 4 MFMAs per (ch, nb) with the
+//     roles swapped -- D^T[cout][pair] = W_k^T[cout][cin] x in^T[cin][pair] -- so that a lane ends up with 4
+//     consecutive output channels of ITS pair, and one 16-B read-modify-write of the wave's LDS accumulator tile.
+// Batches run in ascending offset order and a batch holds distinct output rows (pads go to a dummy row), so the
+// per-output summation order is fixed: deterministic, no atomics.  The epilogue streams the tile out row-major
+// (residual / bias / output statistics / fused BN-backward mask and sums exactly as store_tile).
+constexpr int CR = MS3D_PL_ROWS;
+
+__host__ __device__ constexpr size_t pairlist_wave_floats(int nbt) { return (size_t)(CR + 1) * nbt * 16; }
+
+template <int NBT, int NCH>
+__global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    constexpr int CW = NBT * 16;  // accumulator row width
+    constexpr int F4 = CW / 4;
+    constexpr int CBU = NCH == 1 ? 8 : 4;  // batches whose gathers are in flight together
+    const int l = lane_id(), q = l >> 4, jl = l & 15;
+    const int waves = blockDim.x >> 6;
+    const int nb0 = blockIdx.y * NBT;
+    f32x4 *sW4 = reinterpret_cast<f32x4 *>(lds);  // [(k*NCH + ch)*NBT + nb][lane] -> the 4 k-steps t of that lane
+    const int wslots = p.K * NCH * NBT * 64;
+    float *s_part = lds + (size_t)wslots * 4;  // [2*Cout]
+    float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + (size_t)wave_id() * pairlist_wave_floats(NBT);  // [(CR+1)][CW]
+
+    // weights of this block's column slice: global fragment order [k][ch][t][nb][lane] -> LDS [k][ch][nb][lane][t]
+    for (int e = threadIdx.x; e < wslots; e += blockDim.x) {
+        const int lane = e & 63, r = e >> 6;
+        const int nb = r % NBT, kc = r / NBT;  // kc = k*NCH + ch
+        const float *src = p.wf + ((size_t)kc * 4 * p.NBtot + nb0 + nb) * 64 + lane;
+        f32x4 w;
+#pragma unroll
+        for (int t = 0; t < 4; t++) w[t] = src[(size_t)t * p.NBtot * 64];
+        sW4[e] = w;
+    }
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    for (int e = l; e < (CR + 1) * F4; e += 64) reinterpret_cast<f32x4 *>(acc_t)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // blocks of one XCD take neighbouring tiles
+    if (nblk % 8 != 0) vb = blockIdx.x;
+    const int total_waves = nblk * waves;
+    const int chunk = (p.ntiles + total_waves - 1) / total_waves;  // p.ntiles counts CR-row tiles here
+    const int wglobal = vb * waves + wave_id();
+    const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
+
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};  // per-lane column sums (columns 4*(l % F4)..+3)
+    const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
+    const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
+
+    for (int tile = t_begin; tile < t_end; tile++) {
+        const int row0 = tile * CR;
+        const int b_begin = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile]);
+        const int b_end = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile + 1]);
+        for (int b0 = b_begin; b0 < b_end; b0 += CBU) {
+            int2 ent[CBU];
+            f32x4 a[CBU][NCH];
+#pragma unroll
+            for (int u = 0; u < CBU; u++) ent[u] = entries[(size_t)min(b0 + u, b_end - 1) * 16 + jl];
+#pragma unroll
+            for (int u = 0; u < CBU; u++) {
+                const float *row = p.in + (size_t)ent[u].x * p.Cin + 4 * q;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) a[u][ch] = *reinterpret_cast<const f32x4 *>(row + 16 * ch);
+            }
+            if (p.pre_scale) {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.pre_scale + 16 * ch + 4 * q);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < CBU; u++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float x = fmaf(a[u][ch][t], sc[t], sh[t]);
+                            a[u][ch][t] = p.pre_relu ? fmaxf(x, 0.f) : x;
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CBU; u++) {
+                if (b0 + u >= b_end) break;
+                const int k = ent[u].y >> 8, orow = ent[u].y & 255;
+                f32x4 d[NBT];
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++) d[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) {
+                        const f32x4 w = sW4[((k * NCH + ch) * NBT + nb) * 64 + l];
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            d[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[u][ch][t], d[nb], 0, 0, 0);
+                    }
+                // D^T layout: row = output channel 4q + r, column = pair jl -> 16 contiguous bytes of the pair's row.
+                // Plain read-modify-write: the wave is the only writer of its tile, its LDS operations execute in
+                // order, and inside one batch only pad pairs (dummy row) share an address (LDS float atomics were
+                // measured at ~240 cycles per instruction).
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++) {
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(acc_t + orow * CW + 16 * nb + 4 * q);
+                    f32x4 cur = *dst;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) cur[r] += d[nb][r];
+                    *dst = cur;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- epilogue: CR x CW accumulator tile, row-major, 16 B per lane per step
+#pragma unroll
+        for (int i = 0; i < F4; i++) {
+            const int r = i * (64 / F4) + l / F4;
+            f32x4 *src = reinterpret_cast<f32x4 *>(acc_t + r * CW + 4 * c4);
+            f32x4 o4 = *src;
+            *src = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = row0 + r;
+            if (row < p.Vout) {
+                const size_t o = (size_t)row * p.Cout + col;
+                if (p.residual) {
+                    const f32x4 rs = *reinterpret_cast<const f32x4 *>(p.residual + o);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o4[t] += rs[t];
+                }
+                if (p.bias) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o4[t] += p.bias[col + t];
+                }
+                if (p.bn_x) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(p.bn_x + o);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float z = fmaf(x[t], p.bn_scale[col + t], p.bn_shift[col + t]);
+                        const float g = (z > 0.f) ? o4[t] : 0.f;
+                        o4[t] = g;
+                        st1[t] += g;
+                        st2[t] += g * ((x[t] - p.bn_mean[col + t]) * p.bn_invstd[col + t]);
+                    }
+                } else if (p.out_stats) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        st1[t] += o4[t];
+                        st2[t] = fmaf(o4[t], o4[t], st2[t]);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(p.out + o) = o4;
+            }
+        }
+        // the dummy row collected the pad products; clear it with the rest
+        if (l < F4) reinterpret_cast<f32x4 *>(acc_t + CR * CW)[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (with_partial) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            atomicAdd(&s_part[col + t], st1[t]);
+            atomicAdd(&s_part[p.Cout + col + t], st2[t]);
+        }
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT, int NCH>
+int launch_fwd_pairlist(ConvArgs p, dim3 grid, int threads, size_t lds, hipStream_t stream)
+{
+    p.ntiles = ms3d_divup(p.Vout, CR);
+    if (lds > 64 * 1024)
+        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_pairlist_kernel<NBT, NCH>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    spconv_fwd_pairlist_kernel<NBT, NCH><<<grid, threads, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -722,12 +910,26 @@ namespace {
 struct FwdGeom {
     int nbt, ny, threads, nblk, G;
     size_t lds;
-    bool ok, small;
+    bool ok, small, pairlist;
 };
+constexpr int PAIRLIST_MIN_ROWS = 50000;  // below this the 16-row kernels win (weight staging per block dominates)
+int pairlist_min_rows()
+{
+    static const int v = [] {
+        const char *e = getenv("MS3D_PAIRLIST_MIN_ROWS");  // tuning knob; < 0 disables the pair-list kernels
+        return e ? atoi(e) : PAIRLIST_MIN_ROWS;
+    }();
+    return v;
+}
+bool pairlist_shape_ok(int Vout, int K, int Cin, int Cout)
+{
+    return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0 &&
+           Cin <= 32 && Cout <= 32;
+}
 constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
 // bottom of the U-Net) are spread over the chip by giving each wave fewer output columns and each block fewer waves.
-FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
+FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, bool with_pairlist)
 {
     FwdGeom g{};
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
@@ -754,6 +956,36 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
         g.lds = ((size_t)(ks - 1) * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
         g.ok = ks <= 4 && g.nbt >= 1 && g.nbt <= MAX_NBT;
         return g;
+    }
+    if (with_pairlist && pairlist_shape_ok(Vout, K, Cin, Cout)) {
+        // column split (the gathers are repeated per slice) only when the weight image would starve the block of waves
+        int nbt = NBtot;
+        const size_t spart = (size_t)((2 * Cout + 3) & ~3) * sizeof(float);
+        auto waves_for = [&](int nbt_) {
+            const size_t wbytes = (size_t)K * NCH * 4 * nbt_ * 64 * sizeof(float);
+            const size_t perwave = pairlist_wave_floats(nbt_) * sizeof(float);
+            return wbytes + spart >= LDS_BUDGET ? 0 : (int)((LDS_BUDGET - wbytes - spart) / perwave);
+        };
+        while (nbt > 1 && nbt % 2 == 0 && waves_for(nbt) < 8) nbt /= 2;
+        int W = waves_for(nbt);
+        const int tiles = ms3d_divup(Vout, CR);
+        if (W > 16) W = 16;
+        if (W >= 2) {
+            // every CU gets a block; waves sized so that the static tile chunks come out even
+            const int chunk = ms3d_divup(tiles, 256 * W);
+            const int wfill = ms3d_divup(ms3d_divup(tiles, chunk), 256);
+            if (W > wfill) W = wfill < 2 ? 2 : wfill;
+            g.pairlist = true;
+            g.ny = NBtot / nbt;
+            g.nbt = nbt;
+            g.threads = W * 64;
+            g.nblk = ms3d_divup(tiles, W);
+            if (g.nblk > 256) g.nblk = 256;
+            g.G = K;
+            g.lds = (size_t)K * NCH * 4 * nbt * 64 * sizeof(float) + spart + (size_t)W * pairlist_wave_floats(nbt) * sizeof(float);
+            g.ok = true;
+            return g;
+        }
     }
     int ny = ms3d_divup(NBtot, MAX_NBT);
     while (NBtot % ny != 0) ny++;
@@ -792,9 +1024,11 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial)
 
 extern "C" {
 
-int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout)
+int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27; }
+
+int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist)
 {
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true, with_pairlist != 0);
     return g.nblk * g.ny;
 }
 
@@ -803,22 +1037,30 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
                         const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
-                        const float *bias, ms3d_stream_t stream_)
+                        const float *bias, const int *pl_tile_start, const int *pl_entries, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
     ConvArgs p;
     p.bias = bias;
+    p.pl_tile_start = pl_tile_start; p.pl_entries = pl_entries;
     p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.NCH = ms3d_divup(Cin, 16); p.NBtot = ms3d_divup(Cout, 16); p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr || p.out_stats);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr || p.out_stats, pl_tile_start && pl_entries);
     if (!g.ok) return MS3D_E_UNSUPPORTED;
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
+    if (g.pairlist) {
+        if (g.nbt == 1 && p.NCH == 1) return launch_fwd_pairlist<1, 1>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 1 && p.NCH == 2) return launch_fwd_pairlist<1, 2>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 2 && p.NCH == 1) return launch_fwd_pairlist<2, 1>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 2 && p.NCH == 2) return launch_fwd_pairlist<2, 2>(p, grid, g.threads, g.lds, stream);
+        return MS3D_E_UNSUPPORTED;
+    }
     if (g.small) {
         switch (g.nbt) {
             case 1: return launch_fwd_small<1>(p, grid, g.threads, g.lds, aligned, stream);
@@ -977,8 +1219,12 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
 {
     // weight images (both orientations) + epilogue partials (fwd: Cout wide, bwd: Cin wide) + wgrad slabs + s1s2
     const size_t wf = ms3d_spconv_wf_floats(K, Cin, Cout) + ms3d_spconv_wf_floats(K, Cout, Cin);
-    const size_t pf = (size_t)ms3d_spconv_partial_blocks(Vout, K, Cin, Cout) * 2 * Cout;
-    const size_t pb = (size_t)ms3d_spconv_partial_blocks(Vin, K, Cout, Cin) * 2 * Cin;
+    const auto blocks = [](int V, int K_, int ci, int co) {
+        const int a = ms3d_spconv_partial_blocks(V, K_, ci, co, 0), b = ms3d_spconv_partial_blocks(V, K_, ci, co, 1);
+        return (size_t)(a > b ? a : b);
+    };
+    const size_t pf = blocks(Vout, K, Cin, Cout) * 2 * Cout;
+    const size_t pb = blocks(Vin, K, Cout, Cin) * 2 * Cin;
     const size_t wg = (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout;
     return wf + (pf > pb ? pf : pb) + wg + 2 * (size_t)Cin + 64;
 }
@@ -988,7 +1234,8 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
 int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
                               int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,
                               const float *residual, const float *bias, float *wf_buf, float *y, float *stat_partial,
-                              void *ev_start, void *ev_stop, ms3d_stream_t stream)
+                              const int *pl_tile_start, const int *pl_entries, void *ev_start, void *ev_stop,
+                              ms3d_stream_t stream)
 {
     float *wf = wf_buf, *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     int rc = ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream);
@@ -996,7 +1243,8 @@ int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd
     // optional HIP events bracketing ONLY the convolution kernel, on the stream it is launched on (bench.py roofline)
     if (ev_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     rc = ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, stream);
+                             nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, pl_tile_start,
+                             pl_entries, stream);
     if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return rc;
 }
@@ -1024,22 +1272,25 @@ float ms3d_event_elapsed_ms(void *start, void *stop)
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
-                               int need_dx, float *dx, float *dgb, float *dW, float *ws, ms3d_stream_t stream)
+                               int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *pl_fwd_tile_start,
+                               const int *pl_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
+                               ms3d_stream_t stream)
 {
+    (void)pl_fwd_tile_start; (void)pl_fwd_entries;  // backward-weight still walks the table
     const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     const bool bn = scale != nullptr;
     int rc;
     if (need_dx || bn) {
         if (!bn) {
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
+                                     nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
             if (rc) return rc;
         } else {
             if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
-            const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin);
+            const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, pl_bwd_tile_start && pl_bwd_entries);
             float *partial = ws;
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
-                                     mean, invstd, partial, 0, nullptr, stream);
+                                     mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
             if (rc) return rc;
             rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
             if (rc) return rc;
@@ -1053,7 +1304,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             }
         }
     }
-    float *slabs = ws + (size_t)ms3d_spconv_partial_blocks(Vin, K, Cout, Cin) * 2 * Cin;
+    const int pb0 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 0), pb1 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 1);
+    float *slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
     return ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs, stream);
 }
 

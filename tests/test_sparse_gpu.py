@@ -67,9 +67,20 @@ def test_coordinate_maps_bit_exact(be, oracle):
                                         (48, 48, 27), (64, 32, 27), (112, 112, 27), (96, 112, 8), (32, 16, 1),
                                         (224, 112, 27), (160, 160, 8)])
 def test_conv_kernels_vs_oracle(be, oracle, cin, cout, K):
-    rng = np.random.default_rng(cin * 1000 + cout + K)
     big = cin * cout <= 32 * 32
-    c = surface_coords(rng, 2, 24000 if big else 3000)
+    _check_conv(be, oracle, cin, cout, K, 24000 if big else 3000, 60)
+
+
+@pytest.mark.parametrize("cin,cout,K", [(16, 16, 27), (32, 16, 27), (16, 32, 27), (16, 32, 8), (32, 32, 27), (32, 32, 8)])
+def test_conv_pair_compacted_kernels_vs_oracle(be, oracle, cin, cout, K):
+    """full-resolution sizes (>= 50k output rows) take the pair-compacted kernel (spconv_fwd_compact_kernel)"""
+    V = _check_conv(be, oracle, cin, cout, K, 200000 if K == 27 else 600000, 300 if K == 27 else 400)
+    assert V >= 50000
+
+
+def _check_conv(be, oracle, cin, cout, K, npts, extent):
+    rng = np.random.default_rng(cin * 1000 + cout + K)
+    c = surface_coords(rng, 2, npts, extent)
     V = c.shape[0]
     if K == 27:
         nbr = oracle.kmap_k3(c, 1)
@@ -132,6 +143,7 @@ def test_conv_kernels_vs_oracle(be, oracle, cin, cout, K):
     want_dw2 = oracle.conv_bwd_weight(np.maximum(x * scale + shift, 0), g, nbr, K)
     got_dw2 = be.conv_backward_weight(xd, dev(g), nbr_d, vout, K, cin, cout, pre=(dev(scale), dev(shift)), pre_relu=True)
     assert rel_err(got_dw2.cpu(), torch.from_numpy(want_dw2)) < RTOL
+    return min(vin, vout)
 
 
 @pytest.mark.parametrize("C_", [16, 48, 112])

@@ -1,0 +1,37 @@
+"""Micro-timing of one conv configuration on the bench's level-0 (or level-1) geometry.
+usage: python tools/conv_micro.py [cin cout K level]   (env knobs of the library apply)"""
+import sys, os, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from minsu3d_amd import backend as B
+from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
+
+cin, cout, K, level = (int(a) for a in (sys.argv[1:5] + ["16", "16", "27", "0"][len(sys.argv) - 1:]))
+dev = torch.device("cuda", 0)
+be = B.get_backend()
+batch = bench.make_batch([0, 1, 2, 3], dev)
+cm = CoordinateManager(batch["voxel_xyz"].int().contiguous(), spatial_sort=True)
+ts = 1
+for _ in range(level):
+    cm.k2(ts); ts *= 2
+if K == 27:
+    nbr = cm.k3(ts); vin = vout = cm.size(ts)
+else:
+    nbr, _ = cm.k2(ts); vin, vout = cm.size(ts), cm.size(2 * ts)
+pairs = int((nbr >= 0).sum())
+x = torch.randn(vin, cin, device=dev)
+W = torch.randn(K, cin, cout, device=dev) * 0.05
+wf = be.prep_weights(W, K, cin, cout)
+for _ in range(3):
+    y = be.conv_forward(x, wf, nbr, vout, K, cin, cout)
+torch.cuda.synchronize()
+n = 20
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(n):
+    y = be.conv_forward(x, wf, nbr, vout, K, cin, cout)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / n * 1e3
+alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
+print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic"
+      f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
