@@ -154,6 +154,13 @@ size_t ms3d_kmap_pairlist_capacity(int K, int Vout);
 int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
                              size_t workspace_bytes /* >= ms3d_coord_workspace_bytes(1) */, ms3d_stream_t stream);
 
+/* Offset-major pair list of a table (the classic per-offset in/out index pairs) for the backward-weight kernel:
+ *   kt_start[K * tiles + 1]  first pair of (offset k, 64-row tile t) at [k * tiles + t]; last = number of pairs
+ *   entries[2 * pairs]       int2 per pair: (input row, output row), ascending output row inside an offset */
+size_t ms3d_kmap_offsetlist_capacity(int K, int Vout);
+int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, int *entries, void *workspace,
+                               size_t workspace_bytes, ms3d_stream_t stream);
+
 /* spatial sort keys (batch | 45-bit Morton code): rows sorted by this key keep a voxel's 26 neighbours close in
  * memory, so the conv gathers of one XCD stay inside its own L2 slice */
 int ms3d_morton_keys(const int *coords, int V, long long *keys, ms3d_stream_t stream);
@@ -188,7 +195,9 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
 int ms3d_spconv_wgrad_row_chunks(int Vout);
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
                                 int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
-                                float *partial_ws, ms3d_stream_t stream);
+                                float *partial_ws,
+                                const int *ol_kt_start /* offset list of `nbr` (ms3d_kmap_offsetlist_build) or NULL */,
+                                const int *ol_entries, ms3d_stream_t stream);
 /* One-call layer entry points (forward / backward of a fused [BN -> ReLU ->] conv): same kernels as above, enqueued
  * from native code.  wf_buf holds both weight images (ms3d_spconv_wf_floats(K,Cin,Cout)+(K,Cout,Cin) floats) and is
  * kept by the caller between forward and backward; ws: ms3d_spconv_layer_ws_floats() floats of scratch. */
@@ -207,7 +216,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
                                int need_dx, float *dx, float *dgb, float *dW, float *ws,
-                               const int *pl_fwd_tile_start /* pair list of nbr_fwd or NULL */, const int *pl_fwd_entries,
+                               const int *ol_fwd_kt_start /* offset list of nbr_fwd or NULL */, const int *ol_fwd_entries,
                                const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
                                ms3d_stream_t stream);
 

@@ -401,6 +401,26 @@ class _HipEngine:
             nbr._ms3d_pairlist = pl
         return pl
 
+    def offsetlist(self, nbr, K, vout):
+        """offset-major pair list of a table for the backward-weight kernel, cached on the table tensor
+        -> (kt_start, entries) or (None, None) for small levels"""
+        ol = getattr(nbr, "_ms3d_offsetlist", None)
+        if ol is None:
+            ol = (None, None)
+            if self.lib.ms3d_kmap_pairlist_wanted(int(K), int(vout)):
+                self.lib.ms3d_kmap_offsetlist_capacity.restype = C.c_size_t
+                cap = self.lib.ms3d_kmap_offsetlist_capacity(int(K), int(vout))
+                tiles = self.lib.ms3d_kmap_pairlist_tiles(int(vout))
+                kt_start = torch.empty(K * tiles + 1, dtype=torch.int32, device=nbr.device)
+                entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
+                ws = self._cws(1, nbr.device)
+                _lib.check(self.lib.ms3d_kmap_offsetlist_build(_lib.ptr(nbr), int(K), int(vout), _lib.ptr(kt_start),
+                                                               _lib.ptr(entries), _lib.ptr(ws), C.c_size_t(ws.numel()),
+                                                               _lib.stream_handle()), "ms3d_kmap_offsetlist_build")
+                ol = (kt_start, entries)
+            nbr._ms3d_offsetlist = ol
+        return ol
+
     def conv_forward(self, x, wf, nbr, vout, K, cin, cout, pre=None, pre_relu=False, residual=None, bn_bwd=None,
                      out_stats=False, bias=None):
         """out = sum_k act(x[nbr[k]]) @ Weff[k] (+ residual).  pre = (scale, shift) fuses BN(+ReLU) on the input.
@@ -467,7 +487,7 @@ class _HipEngine:
         dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
         dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
-        plf = self.pairlist(nbr_fwd, K, vout)
+        plf = self.offsetlist(nbr_fwd, K, vout)
         plb = self.pairlist(nbr_bwd, K, vin) if want_dx else (None, None)
         _lib.check(self.lib.ms3d_spconv_layer_backward(
             _lib.ptr(x), _lib.ptr(dy), _lib.ptr(wf_buf), _lib.ptr(nbr_fwd), _lib.ptr(nbr_bwd), int(vin), int(vout), int(K),
@@ -484,10 +504,11 @@ class _HipEngine:
         ps, pb = (pre if pre is not None else (None, None))
         chunks = self.lib.ms3d_spconv_wgrad_row_chunks(int(vout))
         ws = self.ws.get("wgrad", chunks * K * cin * cout * 4, x.device)
+        ol = self.offsetlist(nbr, K, vout)
         _lib.check(self.lib.ms3d_spconv_backward_weight(
             _lib.ptr(x), _lib.ptr(dout), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(dW),
-            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(ws), _lib.stream_handle()),
-            "ms3d_spconv_backward_weight")
+            _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(ws), _lib.ptr(ol[0]), _lib.ptr(ol[1]),
+            _lib.stream_handle()), "ms3d_spconv_backward_weight")
         return dW
 
     # ---- batch norm pieces

@@ -266,6 +266,50 @@ __global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restric
     }
 }
 
+// Offset-major pair lists (the classic in/out index pairs per kernel offset) for the backward-weight kernel:
+// kt_start[k * tiles + tile] = first pair of (offset k, 64-row tile), pairs in ascending output row inside it.
+template <int KT>
+__global__ __launch_bounds__(256) void offsetlist_count_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
+                                                               int *__restrict__ kt_count)
+{
+    const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    if (tile >= tiles) return;
+    const int l = lane_id();
+    const int row = tile * MS3D_PL_ROWS + l;
+    const bool ok = row < Vout;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        const int v = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+        const int n = __popcll(__ballot(v >= 0));
+        if (l == k) mine = n;
+    }
+    if (l < K) kt_count[(size_t)l * tiles + tile] = mine;
+    if (tile == 0 && l == 0) kt_count[(size_t)K * tiles] = 0;  // slot for the grand total
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void offsetlist_fill_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
+                                                              const int *__restrict__ kt_start, int2 *__restrict__ entries)
+{
+    const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    if (tile >= tiles) return;
+    const int l = lane_id();
+    const int row = tile * MS3D_PL_ROWS + l;
+    const bool ok = row < Vout;
+    int v[KT], st[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        v[k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+        st[k] = kt_start[(size_t)min(k, K - 1) * tiles + tile];
+    }
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        const unsigned long long m = __ballot(v[k] >= 0);
+        if (v[k] >= 0) entries[(size_t)st[k] + ballot_rank(m)] = make_int2(v[k], row);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,6 +419,32 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
         pairlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
     else
         pairlist_fill_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t ms3d_kmap_offsetlist_capacity(int K, int Vout) { return (size_t)K * (size_t)(Vout > 0 ? Vout : 0); }
+
+int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, int *entries, void *workspace,
+                               size_t workspace_bytes, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Vout <= 0) return 0;
+    if (K > 27) return MS3D_E_UNSUPPORTED;
+    if (workspace_bytes < ms3d_scan_workspace_bytes()) return MS3D_E_WORKSPACE;
+    const int tiles = ms3d_divup(Vout, MS3D_PL_ROWS);
+    const int grid = ms3d_divup((long)tiles * 64, 256);
+    if (K <= 8)
+        offsetlist_count_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start);
+    else
+        offsetlist_count_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start);
+    MS3D_LAUNCH_CHECK();
+    int rc = ms3d_exclusive_scan_i32(kt_start, kt_start, K * tiles + 1, nullptr, workspace, stream);
+    if (rc) return rc;
+    if (K <= 8)
+        offsetlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start, reinterpret_cast<int2 *>(entries));
+    else
+        offsetlist_fill_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start, reinterpret_cast<int2 *>(entries));
     MS3D_LAUNCH_CHECK();
     return 0;
 }

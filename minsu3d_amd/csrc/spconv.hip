@@ -580,6 +580,8 @@ struct WgradArgs {
     const float *pre_scale;  // fused BN(+ReLU) on `in` (recomputed), or null
     const float *pre_shift;
     int Vout, K, Cin, Cout, NBtot, rows_per_block, pre_relu;
+    const int *ol_kt_start;  // offset-major pair list of the table (ms3d_kmap_offsetlist_build) or null
+    const int *ol_entries;
 };
 
 // grid: x = row chunk, y = offset group (KG offsets), z = 16-channel input chunk.  Rows are the MFMA reduction
@@ -677,21 +679,32 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     }
 }
 
-// dW[e] = sum over row chunks of partial[b][e], fixed order -> deterministic
-__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int nblk, long n, float *__restrict__ dW)
+// dW[e] = sum over row chunks of partial[b][e].  Block = 16 elements x 16 slab lanes: lane j sums slabs j, j+16, ...
+// and the 16 lane sums are combined in lane order -> fixed order, deterministic; 16x the threads of one-thread-per-
+// element (the slab walk is latency-bound: 251 slabs took 21 us).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblk, long n,
+                                                           float *__restrict__ dW)
 {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += partial[(size_t)b * n + e];
-        s1 += partial[(size_t)(b + 1) * n + e];
-        s2 += partial[(size_t)(b + 2) * n + e];
-        s3 += partial[(size_t)(b + 3) * n + e];
+    __shared__ float s_sum[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long e = (long)blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        int b = sl;
+        for (; b + 16 < nblk; b += 32) {
+            s0 += partial[(size_t)b * n + e];
+            s1 += partial[(size_t)(b + 16) * n + e];
+        }
+        if (b < nblk) s0 += partial[(size_t)b * n + e];
     }
-    for (; b < nblk; b++) s0 += partial[(size_t)b * n + e];
-    dW[e] = (s0 + s1) + (s2 + s3);
+    s_sum[sl][el] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) t += s_sum[j][threadIdx.x];
+        dW[e] = t;
+    }
 }
 
 template <int KG, int NBT>
@@ -699,6 +712,199 @@ int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 {
     dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
     spconv_wgrad_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward-weight over an offset-major pair list.  Every MFMA step multiplies 4 REAL pairs (the table walk above spends
+// a step on 4 consecutive output rows of which ~1 in 6 has the neighbour at full resolution).
+// Block = one chunk of output tiles x ALL offsets (x one 16-channel input chunk).  The chunk's pairs, concatenated in
+// offset order, are cut into equal slices, one per wave.  A wave that owns all of an offset's pairs stores that
+// offset's slab directly; offsets cut by a slice boundary park their partial sums in LDS and are combined in wave
+// order after one barrier: deterministic.
+// Row gathers: the MFMA wants A[m = ci][k = pair] / B[k = pair][n = co], i.e. ONE float per lane and step; as global
+// loads that is 2 dword gathers per 4 pairs (measured 64 us for 2.3 M pairs).  Instead a lane fetches 16 B of its
+// pair's row (16 pairs x 64 B per instruction, as in the forward kernel), the wave parks the 16x16 tiles in its
+// private LDS area and reads them back transposed (ds_read_b32, conflict-free): 4x fewer vector-memory instructions
+// (55 us).  Tried and measured slower: a grid over (offset, pair range) (63 us), waves that own fixed offsets and
+// sweep the chunk in lock step with a barrier per 256 rows (L2 requests / 3, but 82 us: two dependent round trips
+// per sub-chunk), 4 instead of 2 batches per trip (60 us).
+constexpr int WGRAD_TB = 2;  // 16-pair batches per trip
+
+template <int NBT>
+__global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs p)
+{
+    constexpr int TB = WGRAD_TB;
+    extern __shared__ float lds[];
+    __shared__ int s_lo[32], s_cum[33], s_pk[16][2];
+    const int l = lane_id(), q = l >> 4, cl = l & 15;
+    const int nw = blockDim.x >> 6, w = wave_id();
+    float *s_part = lds;                                                   // [nw][2][NBT*256]
+    float *s_tile = lds + (size_t)nw * 2 * NBT * 256 + (size_t)w * TB * (1 + NBT) * 256;  // [TB][1 + NBT][16 pairs][16]
+    const int tiles = (p.Vout + MS3D_PL_ROWS - 1) / MS3D_PL_ROWS;
+    const int tpb = p.rows_per_block / MS3D_PL_ROWS;  // rows_per_block is a multiple of the tile size here
+    const int t_lo = min(tiles, (int)blockIdx.x * tpb), t_hi = min(tiles, t_lo + tpb);
+    if (w == 0) {
+        const int kk = min(l, p.K - 1);
+        const int lo = p.ol_kt_start[(size_t)kk * tiles + t_lo], hi = p.ol_kt_start[(size_t)kk * tiles + t_hi];
+        const int n = l < p.K ? hi - lo : 0;
+        const int incl = wave_incl_scan(n);
+        if (l < p.K) {
+            s_lo[l] = lo;
+            s_cum[l] = incl - n;
+        }
+        if (l == p.K - 1) s_cum[p.K] = incl;
+    }
+    if (threadIdx.x < 32) s_pk[threadIdx.x >> 1][threadIdx.x & 1] = -1;
+    __syncthreads();
+
+    const int c0 = blockIdx.z * 16 + 4 * q;  // first of the 4 input channels this lane fetches
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.pre_scale) {
+        sc = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
+        sh = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
+    }
+    const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.ol_entries);
+    float *slab = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+
+    const int T = s_cum[p.K];
+    const int s0 = (int)((long long)T * w / nw), s1 = (int)((long long)T * (w + 1) / nw);
+    int n_partial = 0;
+    for (int k = 0; k < p.K; k++) {
+        const int c_lo = s_cum[k], c_hi = s_cum[k + 1];
+        const int g_lo = max(s0, c_lo), g_hi = min(s1, c_hi);
+        if (g_lo >= g_hi) continue;  // wave-uniform
+        const int pbase = s_lo[k] - c_lo;  // list position of concatenated index g = pbase + g
+        const int p_begin = pbase + g_lo, p_end = pbase + g_hi;
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // pipeline: entries two trips ahead, row gathers one trip ahead of the MFMAs (`opaque0` keeps the compiler
+        // from merging the in-loop loads with the ones in front of the loop, which would undo the prefetch)
+        int2 e[TB];
+        f32x4 ga[TB], gb[TB][NBT];
+        auto load_entries = [&](int base) {
+#pragma unroll
+            for (int t = 0; t < TB; t++) e[t] = entries[min(base + 16 * t + cl, p_end - 1)];
+        };
+        auto gather = [&]() {
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                ga[t] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)e[t].x * p.Cin + c0);
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++)
+                    gb[t][nb] = *reinterpret_cast<const f32x4 *>(p.dout + (size_t)e[t].y * p.Cout + 16 * nb + 4 * q);
+            }
+        };
+        load_entries(p_begin);
+        gather();
+        load_entries(p_begin + 16 * TB + opaque0);
+        for (int base = p_begin; base < p_end; base += 16 * TB) {
+            f32x4 ca[TB], cb[TB][NBT];
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                ca[t] = ga[t];
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++) cb[t][nb] = gb[t][nb];
+            }
+            gather();                                        // rows of trip + 1 (entries already here)
+            load_entries(base + 2 * 16 * TB + opaque0);      // entries of trip + 2
+            // current trip: activation + zero the pairs beyond the range, park, read back transposed, multiply
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                const bool ok = base + 16 * t + cl < p_end;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float v = ca[t][i];
+                    if (p.pre_scale) {
+                        v = fmaf(v, sc[i], sh[i]);
+                        if (p.pre_relu) v = fmaxf(v, 0.f);
+                    }
+                    ca[t][i] = ok ? v : 0.f;
+                }
+                float *ta = s_tile + (size_t)t * (1 + NBT) * 256;
+                *reinterpret_cast<f32x4 *>(ta + cl * 16 + 4 * q) = ca[t];
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++) *reinterpret_cast<f32x4 *>(ta + (1 + nb) * 256 + cl * 16 + 4 * q) = cb[t][nb];
+            }
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                const float *ta = s_tile + (size_t)t * (1 + NBT) * 256;
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    const float av = ta[(4 * st + q) * 16 + cl];  // A[m = ci cl][k = pair 4st + q]
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) {
+                        const float bv = ta[(1 + nb) * 256 + (4 * st + q) * 16 + cl];  // B[k = pair][n = co cl]
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D layout: row (input channel within the chunk) = 4q + reg, column (output channel) = cl
+        if (g_lo == c_lo && g_hi == c_hi) {
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
+                    if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[nb][r];
+                }
+        } else {
+            float *dst = s_part + (size_t)(w * 2 + n_partial) * NBT * 256;
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[nb * 256 + r * 64 + l] = acc[nb][r];
+            if (l == 0) s_pk[w][n_partial] = k;
+            n_partial++;  // at most 2: the offsets cut by the two ends of the slice
+        }
+    }
+    __syncthreads();
+    // offsets cut by slice boundaries (partials summed in wave order) and offsets without pairs in this chunk (zeros)
+    for (int k = w; k < p.K; k += nw) {
+        const bool empty = s_cum[k + 1] == s_cum[k];
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bool any = false;
+        for (int ww = 0; ww < nw; ww++)
+            for (int jj = 0; jj < 2; jj++)
+                if (s_pk[ww][jj] == k) {
+                    any = true;
+                    const float *src = s_part + (size_t)(ww * 2 + jj) * NBT * 256;
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[nb][r] += src[nb * 256 + r * 64 + l];
+                }
+        if (any || empty) {
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
+                    if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[nb][r];
+                }
+        }
+    }
+}
+
+template <int NBT>
+int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t stream)
+{
+    // per wave: WGRAD_TB x (1 + NBT) transposition tiles + 2 x NBT boundary partials, 1 KB each
+    const size_t per_wave = ((size_t)WGRAD_TB * (1 + NBT) + 2 * NBT) * 256 * sizeof(float);
+    int nw = (int)(LDS_BUDGET / per_wave);
+    if (nw > 16) nw = 16;
+    dim3 grid(nblk_rows, 1, ms3d_divup(p.Cin, 16));
+    const size_t lds = (size_t)nw * per_wave;
+    if (lds > 64 * 1024)
+        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_offsetlist_kernel<NBT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    spconv_wgrad_offsetlist_kernel<NBT><<<grid, nw * 64, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -717,11 +923,27 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(const float *__
     const int cl = threadIdx.x & 15, lp = threadIdx.x >> 4;  // 16 columns x 64 part lanes
     const int c = blockIdx.x * 16 + cl;
     double a1 = 0.0, a2 = 0.0;
-    if (c < C)
-        for (int p = lp; p < nparts; p += 64) {
+    if (c < C) {
+        // 4 rows per trip, loads issued together (a one-row loop pays one memory round trip per row: 13 us for 1024 rows)
+        int p = lp;
+        for (; p + 192 < nparts; p += 256) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v1[u] = partial[((size_t)(p + 64 * u) * 2 + 0) * C + c];
+                v2[u] = partial[((size_t)(p + 64 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a1 += (double)v1[u];
+                a2 += (double)v2[u];
+            }
+        }
+        for (; p < nparts; p += 64) {
             a1 += (double)partial[((size_t)p * 2 + 0) * C + c];
             a2 += (double)partial[((size_t)p * 2 + 1) * C + c];
         }
+    }
     s_1[lp][cl] = a1;
     s_2[lp][cl] = a2;
     __syncthreads();
@@ -1090,14 +1312,18 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
 int ms3d_spconv_wgrad_row_chunks(int Vout)
 {
     // ~1024+ waves in flight at full resolution, at most 256 partial slabs (the slab reduction reads chunks * |dW|)
+    static const int max_chunks = [] {
+        const char *e = getenv("MS3D_WGRAD_MAX_CHUNKS");  // tuning knob
+        return e ? atoi(e) : 256;
+    }();
     int chunks = ms3d_divup(Vout, 256);
-    if (chunks > 256) chunks = 256;
+    if (chunks > max_chunks) chunks = max_chunks;
     return chunks < 1 ? 1 : chunks;
 }
 
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                 float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
-                                float *partial_ws, ms3d_stream_t stream_)
+                                float *partial_ws, const int *ol_kt_start, const int *ol_entries, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const long n = (long)K * Cin * Cout;
@@ -1109,11 +1335,21 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     p.in = in; p.dout = dout; p.nbr = nbr; p.partial = partial_ws; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = ms3d_divup(Cout, 16); p.pre_relu = pre_relu;
     const int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
-    p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
+    const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 2 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
+    p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
+    const int gran = use_list ? MS3D_PL_ROWS : 16;
+    p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), gran) * gran;
     const int nblk = ms3d_divup(Vout, p.rows_per_block);
     const int nb = p.NBtot;
     if (nb > 14) return MS3D_E_UNSUPPORTED;
     int rc;
+    if (use_list) {
+        rc = nb == 1 ? launch_wgrad_offsetlist<1>(p, nblk, stream) : launch_wgrad_offsetlist<2>(p, nblk, stream);
+        if (rc) return rc;
+        wgrad_reduce_kernel<<<ms3d_divup(n, 16), 256, 0, stream>>>(partial_ws, nblk, n, dW);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    }
     // KG * NBT <= 28 accumulators of 4 VGPRs
     if (nb == 1) rc = (K >= 27) ? launch_wgrad<9, 1>(p, nblk, stream) : launch_wgrad<8, 1>(p, nblk, stream);
     else if (nb == 2) rc = (K >= 27) ? launch_wgrad<9, 2>(p, nblk, stream) : launch_wgrad<8, 2>(p, nblk, stream);
@@ -1127,7 +1363,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     else if (nb <= 12) rc = launch_wgrad<2, 12>(p, nblk, stream);
     else rc = launch_wgrad<2, 14>(p, nblk, stream);
     if (rc) return rc;
-    wgrad_reduce_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(partial_ws, nblk, n, dW);
+    wgrad_reduce_kernel<<<ms3d_divup(n, 16), 256, 0, stream>>>(partial_ws, nblk, n, dW);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1272,11 +1508,10 @@ float ms3d_event_elapsed_ms(void *start, void *stop)
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
-                               int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *pl_fwd_tile_start,
-                               const int *pl_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
+                               int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *ol_fwd_kt_start,
+                               const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
                                ms3d_stream_t stream)
 {
-    (void)pl_fwd_tile_start; (void)pl_fwd_entries;  // backward-weight still walks the table
     const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     const bool bn = scale != nullptr;
     int rc;
@@ -1306,7 +1541,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     }
     const int pb0 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 0), pb1 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 1);
     float *slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
-    return ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs, stream);
+    return ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs,
+                                       ol_fwd_kt_start, ol_fwd_entries, stream);
 }
 
 }  // extern "C"

@@ -234,3 +234,42 @@ def test_mini_unet_eval_mode_backward_hip_vs_torch(be):
             assert rel_err(got[n], p.grad) < 2e-3, n
     finally:
         backend.set_backend(prev)
+
+
+@pytest.mark.parametrize("K", [27, 8])
+def test_pair_lists_bit_exact(be, oracle, K):
+    """tile-major (forward) and offset-major (backward-weight) pair lists vs a numpy restatement of their definition"""
+    rng = np.random.default_rng(K)
+    c = surface_coords(rng, 2, 200000 if K == 27 else 600000, 300 if K == 27 else 400)
+    if K == 27:
+        nbr = oracle.kmap_k3(c, 1).T.copy()                  # [K, V]
+    else:
+        oc, par, ko = oracle.downsample(c, 1)
+        nbr = oracle.kmap_k2(par, ko, oc.shape[0])[0].T.copy()
+    V = nbr.shape[1]
+    assert V >= 50000
+    nbr_d = dev(nbr)
+    tile_start, entries = be.pairlist(nbr_d, K, V)
+    kt_start, pairs = be.offsetlist(nbr_d, K, V)
+    tiles = (V + 63) // 64
+    # offset-major: exact pairs in (k, output row) order
+    kk, rows = np.nonzero(nbr >= 0)
+    want_pairs = np.stack([nbr[kk, rows], rows], 1).astype(np.int32)
+    n = want_pairs.shape[0]
+    assert int(kt_start[-1]) == n
+    assert np.array_equal(pairs[:n].cpu().numpy(), want_pairs)
+    cnt = np.zeros((K, tiles), np.int64)
+    np.add.at(cnt, (kk, rows // 64), 1)
+    assert np.array_equal(kt_start.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt.reshape(-1))]))
+    # tile-major: per (tile, k) group padded to 16
+    nb = (cnt.T + 15) // 16                                  # [tiles, K]
+    want_ts = np.concatenate([[0], np.cumsum(nb.sum(1))])
+    assert np.array_equal(tile_start.cpu().numpy(), want_ts)
+    ent = entries[:16 * int(want_ts[-1])].cpu().numpy()
+    starts = 16 * (want_ts[:-1, None] + np.cumsum(nb, 1) - nb)   # first entry of every (tile, k) group
+    for t in rng.integers(0, tiles, 40):
+        for k in range(K):
+            r = np.nonzero(nbr[k, t * 64:(t + 1) * 64] >= 0)[0]
+            seg = ent[starts[t, k]: starts[t, k] + 16 * nb[t, k]]
+            assert np.array_equal(seg[:len(r), 0], nbr[k, t * 64 + r]) and np.array_equal(seg[:len(r), 1], (k << 8) | r)
+            assert np.all(seg[len(r):, 0] == 0) and np.all(seg[len(r):, 1] == ((k << 8) | 64))

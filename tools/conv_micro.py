@@ -32,6 +32,14 @@ for _ in range(n):
     y = be.conv_forward(x, wf, nbr, vout, K, cin, cout)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
+g = torch.randn(vout, cout, device=dev)
+for _ in range(3):
+    dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
+e0.record()
+for _ in range(n):
+    dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
+e1.record(); torch.cuda.synchronize()
+us_w = e0.elapsed_time(e1) / n * 1e3
 alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
-print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic"
+print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | wgrad {us_w:.1f} us"
       f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
