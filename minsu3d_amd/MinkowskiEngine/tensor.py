@@ -52,6 +52,18 @@ class CoordinateManager:
             self._k2[ts] = be.kmap_k2(parent, koff, oc.size(0))
         return self._k2[ts]
 
+    def prepare(self, n_levels):
+        """build the coordinate sets and kernel maps of `n_levels` U-Net levels now.  Each stride-2 map needs the
+        coarse voxel count on the host (one sync); done up front the syncs hit an almost empty queue, done lazily
+        inside the network each one drains the convolutions queued before it and the GPU then idles while the host
+        catches up."""
+        ts = 1
+        for lvl in range(n_levels):
+            self.k3(ts)
+            if lvl + 1 < n_levels:
+                self.k2(ts)
+            ts *= 2
+
     def identity(self, ts):
         if ts not in self._ident:
             V = self.coords[ts].size(0)

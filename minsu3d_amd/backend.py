@@ -252,7 +252,8 @@ class KernelTimer:
     after the kernel on the stream it is launched on, and keeps the algorithmic byte count of each launch
     (SURVEY 8d formula with the table's real pair count)."""
 
-    def __init__(self, select, lib):
+    def __init__(self, select, lib, max_records=112):
+        self.max_records = max_records  # sampling: event create/record per launch is host time inside the timed region
         self.select = select            # (name, K, cin, cout) -> bool
         self.lib = lib
         lib.ms3d_event_create.restype = C.c_void_p
@@ -262,7 +263,7 @@ class KernelTimer:
         self.enabled = False
 
     def begin(self, name, K, cin, cout, nbr):
-        if not self.enabled or not self.select(name, K, cin, cout):
+        if not self.enabled or len(self.records) >= self.max_records or not self.select(name, K, cin, cout):
             return None
         key = (nbr.data_ptr(), nbr.numel())
         if key not in self._pairs:

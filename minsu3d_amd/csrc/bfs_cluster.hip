@@ -95,8 +95,11 @@ __global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited
 
 // one wave per point, lanes stride its neighbour list.  The root of i is resolved once per wave; an edge whose
 // neighbour already points at that root is dismissed with one cached load (a stale parent[j] == root(i) is still
-// proof of membership: sets only ever merge), so the atomic find/union chain runs for the few merging edges only.
-__global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
+// proof of membership: sets only ever merge), so the label test and the atomic find/union chain run for the few
+// merging edges only.  The kernel is bound by the rate of these random 4-byte reads (170 M edges per step), so when
+// the caller knows the graph is symmetric (no list was cut at the cap) only the j < i half of every list is looked at:
+// the other half is the same undirected edge seen from the other end.
+__global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symmetric, const int16_t *__restrict__ sem,
                                                        const int *__restrict__ ball_idx,
                                                        const int *__restrict__ start_len, int *parent)
 {
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, const int
             int j = i;
             if (t < ln) {
                 j = ball_idx[st + t];
-                if (j != i && (thr.mode != 0 || (int)sem[j] == lab)) merge = parent[j] != ri;  // bfs_cluster.cpp:44
+                if (j != i && (!symmetric || j < i)) {
+                    if (parent[j] != ri) merge = thr.mode != 0 || (int)sem[j] == lab;  // bfs_cluster.cpp:44
+                }
             }
             if (__ballot(merge) == 0ull) continue;
             if (merge) uf_union(parent, i, j);
@@ -503,7 +508,8 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
                                            w.counters);
     MS3D_LAUNCH_CHECK();
-    bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+    bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
+                                                                         w.parent);
     MS3D_LAUNCH_CHECK();
     bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
     MS3D_LAUNCH_CHECK();
@@ -598,7 +604,8 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
                                            w.counters);
         MS3D_LAUNCH_CHECK();
-        bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+        bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
+                                                                         w.parent);
         MS3D_LAUNCH_CHECK();
         bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
         MS3D_LAUNCH_CHECK();

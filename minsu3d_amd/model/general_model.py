@@ -32,7 +32,10 @@ class GeneralModel(nn.Module):
     def configure_optimizers(self):
         opt = dict(self.hparams.cfg.model.optimizer)
         mod, _, name = opt.pop("_target_").rpartition(".")
-        return getattr(importlib.import_module(mod), name)(params=self.parameters(), **opt)
+        params = list(self.parameters())
+        if name in ("Adam", "AdamW") and "fused" not in opt and params and params[0].is_cuda:
+            opt["fused"] = True   # one launch per step instead of ~30 foreach launches with host gaps in between
+        return getattr(importlib.import_module(mod), name)(params=params, **opt)
 
     def forward(self, data_dict):
         return self.backbone(data_dict["voxel_features"], data_dict["voxel_xyz"], data_dict["voxel_point_map"])

@@ -33,9 +33,11 @@ class Backbone(nn.Module):
             ME.MinkowskiReLU(inplace=True))
         self.semantic_branch = _head(m, sem_classes)
         self.offset_branch = _head(m, 3)
+        self.n_levels = len(block_channels)
 
     def forward(self, voxel_features, voxel_coordinates, v2p_map):
         x = ME.SparseTensor(features=voxel_features, coordinates=voxel_coordinates)
+        x.coordinate_manager.prepare(self.n_levels)
         point_features = ME.gather_rows(self.unet(x).features, v2p_map)   # voxel -> point broadcast
         return {"point_features": point_features,
                 "semantic_scores": self.semantic_branch(point_features),
@@ -52,4 +54,5 @@ class TinyUnet(nn.Module):
                                   ME.MinkowskiBatchNorm(channel), ME.MinkowskiReLU(inplace=True))
 
     def forward(self, proposals_voxel_feats):
+        proposals_voxel_feats.coordinate_manager.prepare(2)
         return self.unet(proposals_voxel_feats)
