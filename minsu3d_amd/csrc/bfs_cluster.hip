@@ -120,7 +120,13 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
                 }
             }
             if (__ballot(merge) == 0ull) continue;
-            if (merge) uf_union(parent, i, j);
+            // 64 lanes hooking onto the SAME root one CAS at a time serialise (one winner per round); instead every
+            // lane resolves its own neighbour's root, the wave agrees on the smallest root in sight and each distinct
+            // root is hooked under it: the CAS targets are distinct, one round in the common case
+            const int rj = merge ? uf_find(parent, j) : INT_BIG;
+            const int rmin = min(wave_min(rj), ri);
+            if (merge && rj != rmin) uf_union(parent, rj, rmin);
+            if (ri != rmin && lane_id() == 0) uf_union(parent, ri, rmin);
             ri = uf_find(parent, i);  // refreshed for the next 64 edges
         }
     }
