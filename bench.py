@@ -177,7 +177,7 @@ def main():
                         traffic = int(json.load(f)["traffic_bytes_per_launch"])
                 line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                    "kernel": "spconv_fwd_kernel<1,true> (3x3x3 16->16 gather/MFMA at full resolution, forward launches)",
+                                    "kernel": "spconv_fwd_pairlist_kernel<1,1> (3x3x3 16->16 pair-list gather/MFMA at full resolution, forward launches)",
                                     "launches": s["launches"], "avg_us": round(s["avg_ms"] * 1e3, 2),
                                     "algorithmic_bytes_per_launch": int(s["avg_bytes"])}
         if world == 1 and not args.no_cpu_baseline:
