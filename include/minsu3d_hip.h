@@ -233,6 +233,20 @@ int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const fl
                         const float *mean, const float *invstd, int relu, float *dz, float *partial_ws,
                         int partial_rows, int *nparts_out /*[host]*/, ms3d_stream_t stream);
 
+/* ======================================================================================
+ * Instance post-processing (validation / test time): replaces the dense [P, N] mask algebra of
+ * model/pointgroup.py:197-265 (cross IoU by mask matrix product on the host + numpy greedy NMS).
+ * ====================================================================================== */
+/* inter[a][b] = number of points shared by proposals a and b (diagonal = proposal sizes).  The (cluster, point) pairs
+ * must be unique and sorted by point: pair_point[S] ascending, pair_cluster[S] the proposal of each pair. */
+int ms3d_proposal_cross_intersection(const int *pair_point, const int *pair_cluster, int S, int P, int *inter /*[P,P]*/,
+                                     ms3d_stream_t stream);
+/* greedy non-maximum suppression in the given order (descending score): a proposal is picked unless an earlier pick
+ * has IoU = inter/(n_a+n_b-inter) > threshold with it (float32, as the reference).  pick[P], *n_pick on the device;
+ * suppressed_ws: P bytes of scratch. */
+int ms3d_nms_greedy(const int *inter, const int *order, int P, float threshold, unsigned char *suppressed_ws, int *pick,
+                    int *n_pick, ms3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -450,6 +450,28 @@ class _HipEngine:
                                                  _lib.stream_handle()), "ms3d_reduce_partials")
         return out, s1s2
 
+    # ---- instance post-processing (validation / test)
+    def proposal_cross_intersection(self, pair_point, pair_cluster, P):
+        """unique (cluster, point) pairs sorted by point -> int32 [P, P] shared-point counts (sizes on the diagonal)"""
+        pair_point = self._dev(pair_point).to(torch.int32).contiguous()
+        pair_cluster = self._dev(pair_cluster).to(torch.int32).contiguous()
+        inter = torch.empty((P, P), dtype=torch.int32, device=pair_point.device)
+        _lib.check(self.lib.ms3d_proposal_cross_intersection(_lib.ptr(pair_point), _lib.ptr(pair_cluster),
+                                                             int(pair_point.numel()), int(P), _lib.ptr(inter),
+                                                             _lib.stream_handle()), "ms3d_proposal_cross_intersection")
+        return inter
+
+    def nms_greedy(self, inter, order, threshold):
+        """greedy NMS over `order` (descending score) -> picked proposal ids in pick order (device int32)"""
+        inter = self._dev(inter); order = self._dev(order).to(torch.int32).contiguous()
+        P = inter.size(0)
+        pick = torch.empty(max(P, 1), dtype=torch.int32, device=inter.device)
+        n_pick = torch.zeros(1, dtype=torch.int32, device=inter.device)
+        ws = torch.empty(max(P, 1), dtype=torch.uint8, device=inter.device)
+        _lib.check(self.lib.ms3d_nms_greedy(_lib.ptr(inter), _lib.ptr(order), int(P), C.c_float(threshold), _lib.ptr(ws),
+                                            _lib.ptr(pick), _lib.ptr(n_pick), _lib.stream_handle()), "ms3d_nms_greedy")
+        return pick[:int(n_pick.item())]
+
     # ---- one library call per layer and direction (used by MinkowskiEngine/functional.py)
     def conv_layer_forward(self, x, W3, nbr_fwd, vout, K, cin, cout, mirror_bwd, pre, pre_relu, residual, bias,
                            want_stats):

@@ -87,3 +87,11 @@ class HAIS(GeneralModel):
         target = get_segmented_scores(ious.max(1)[0], net.fg_thresh, net.bg_thresh)
         losses["score_loss"] = nn.functional.binary_cross_entropy_with_logits(scores.view(-1), target)
         return losses
+
+    def _get_pred_instances(self, scan_id, gt_xyz, scores, proposals_idx, num_proposals, mask_scores, semantic_scores,
+                            num_ignored_classes):
+        """same name and arguments as the reference (hais.py:210); tensors may stay on the device"""
+        from .postprocess import hais_instances
+        t = self.hparams.cfg.model.network.test
+        return hais_instances(scan_id, gt_xyz, scores, proposals_idx, num_proposals, mask_scores, semantic_scores,
+                              num_ignored_classes, t.test_mask_score_thre, t.TEST_SCORE_THRESH, t.TEST_NPOINT_THRESH)

@@ -84,3 +84,11 @@ class PointGroup(GeneralModel):
             else:
                 losses["score_loss"] = scores.sum() * 0
         return losses
+
+    def _get_pred_instances(self, scan_id, gt_xyz, proposals_scores, proposals_idx, num_proposals, semantic_scores,
+                            num_ignored_classes):
+        """same name and arguments as the reference (pointgroup.py:197-199); tensors may stay on the device"""
+        from .postprocess import pointgroup_instances
+        t = self.hparams.cfg.model.network.test
+        return pointgroup_instances(scan_id, gt_xyz, proposals_scores, proposals_idx, num_proposals, semantic_scores,
+                                    num_ignored_classes, t.TEST_SCORE_THRESH, t.TEST_NPOINT_THRESH, t.TEST_NMS_THRESH)

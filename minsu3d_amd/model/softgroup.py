@@ -163,3 +163,12 @@ class SoftGroup(GeneralModel):
         err = nn.functional.mse_loss(output_dict["iou_scores"][prop, labels], target, reduction="none")
         losses["iou_scoring_loss"] = err[w].sum() / (w.count_nonzero() + 1)
         return losses
+
+    def _get_pred_instances(self, scan_id, gt_xyz, proposals_idx, num_points, cls_scores, iou_scores, mask_scores,
+                            num_ignored_classes):
+        """same name and arguments as the reference (softgroup.py:269-270); tensors may stay on the device"""
+        from .postprocess import softgroup_instances
+        t = self.hparams.cfg.model.network.test_cfg
+        return softgroup_instances(scan_id, gt_xyz, proposals_idx, num_points, cls_scores, iou_scores, mask_scores,
+                                   num_ignored_classes, self.instance_classes, t.cls_score_thr, t.mask_score_thr,
+                                   t.min_npoint)

@@ -80,6 +80,15 @@ class OracleBackend:
         a, b = O.get_mask_label(_np(pi), _np(po), _np(il), _np(ic), _np(iou), ignored_label, iou_thr)
         return _t(a), _t(b)
 
+    # ---------------------------------------------------------------- instance post-processing
+    def proposal_cross_intersection(self, pair_point, pair_cluster, P):
+        from . import postprocess_oracle as PO
+        return _t(PO.cross_intersection(_np(pair_point), _np(pair_cluster), P))
+
+    def nms_greedy(self, inter, order, threshold):
+        from . import postprocess_oracle as PO
+        return _t(PO.nms_from_counts(_np(inter), _np(order), threshold))
+
     # ---------------------------------------------------------------- coordinates (tables offset-major [K, V])
     def sparse_quantize(self, coords):
         u, inv = O.sparse_quantize(_np(coords))
