@@ -247,6 +247,15 @@ int ms3d_proposal_cross_intersection(const int *pair_point, const int *pair_clus
 int ms3d_nms_greedy(const int *inter, const int *order, int P, float threshold, unsigned char *suppressed_ws, int *pick,
                     int *n_pick, ms3d_stream_t stream);
 
+/* ======================================================================================
+ * Augmentation: elastic distortion (util/transform.py:65-84, called twice per training scene from
+ * data/dataset/general_dataset.py:118-120).  noise: three float32 grids [3][bx][by][bz] drawn by the caller
+ * (host RNG, same shapes/order as the reference), blurred in place (noise_tmp: same size scratch);
+ * out = xyz + mag * trilinear(noise)(xyz), float64, grid nodes at linspace(-(b-1)*gran, (b-1)*gran, b).
+ * ====================================================================================== */
+int ms3d_elastic_distort(const double *xyz /*[N,3]*/, int N, float *noise, float *noise_tmp, int bx, int by, int bz,
+                         double gran, double mag, double *out /*[N,3]*/, ms3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

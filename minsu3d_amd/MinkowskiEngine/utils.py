@@ -37,7 +37,7 @@ def sparse_collate(coords, feats, labels=None, dtype=torch.int32, device=None):
     bc, bf = [], []
     for b, (c, f) in enumerate(zip(coords, feats)):
         c = torch.as_tensor(c).to(dtype)
-        bc.append(torch.cat([torch.full((c.size(0), 1), b, dtype=dtype), c], 1))
+        bc.append(torch.cat([torch.full((c.size(0), 1), b, dtype=dtype, device=c.device), c], 1))
         bf.append(torch.as_tensor(f, dtype=torch.float32))
     bc, bf = torch.cat(bc, 0), torch.cat(bf, 0)
     if device is not None:

@@ -450,6 +450,19 @@ class _HipEngine:
                                                  _lib.stream_handle()), "ms3d_reduce_partials")
         return out, s1s2
 
+    # ---- augmentation
+    def elastic(self, xyz, noise, gran, mag):
+        """xyz [N,3] (voxel units), noise float32 [3,bx,by,bz] from the host RNG -> float64 [N,3] distorted points"""
+        xyz = self._dev(xyz).to(torch.float64).contiguous()
+        noise = self._dev(noise).to(torch.float32).contiguous().clone()
+        tmp = torch.empty_like(noise)
+        out = torch.empty_like(xyz)
+        _, bx, by, bz = noise.shape
+        _lib.check(self.lib.ms3d_elastic_distort(_lib.ptr(xyz), int(xyz.size(0)), _lib.ptr(noise), _lib.ptr(tmp), int(bx),
+                                                 int(by), int(bz), C.c_double(gran), C.c_double(mag), _lib.ptr(out),
+                                                 _lib.stream_handle()), "ms3d_elastic_distort")
+        return out
+
     # ---- instance post-processing (validation / test)
     def proposal_cross_intersection(self, pair_point, pair_cluster, P):
         """unique (cluster, point) pairs sorted by point -> int32 [P, P] shared-point counts (sizes on the diagonal)"""

@@ -80,6 +80,13 @@ class OracleBackend:
         a, b = O.get_mask_label(_np(pi), _np(po), _np(il), _np(ic), _np(iou), ignored_label, iou_thr)
         return _t(a), _t(b)
 
+    # ---------------------------------------------------------------- augmentation
+    def elastic(self, xyz, noise, gran, mag):
+        from minsu3d_amd.util import transform as T    # the host restatement pinned against the reference's elastic()
+        x = _np(xyz).astype(np.float64)
+        grids = [T.blur_noise(g) for g in _np(noise).astype(np.float32)]
+        return _t(x + np.hstack([T.trilinear(g, gran, x)[:, None] for g in grids]) * mag)
+
     # ---------------------------------------------------------------- instance post-processing
     def proposal_cross_intersection(self, pair_point, pair_cluster, P):
         from . import postprocess_oracle as PO
