@@ -1,0 +1,130 @@
+"""Train / validate / checkpoint loop -- the part of the reference that PyTorch-Lightning + its callbacks provide
+(`config/model/base.yaml:11-28`, `train.py:17-41`, `general_model.py:56-110`, per-model `validation_step`s):
+epochs over the train loader, cosine decay at every epoch end, validation + `epoch=<n>.ckpt` every
+`check_val_every_n_epoch` epochs, resume from a checkpoint.
+
+Checkpoints use Lightning's top-level keys (`epoch`, `global_step`, `state_dict`, `optimizer_states`), so a reference
+`.ckpt` (README.md:146-151) loads through `load_checkpoint` as well: parameter names follow the reference modules
+(SURVEY Appendix D)."""
+import os
+
+import numpy as np
+import torch
+
+from .evaluation import (GeneralDatasetEvaluator, evaluate_bbox_acc, evaluate_semantic_accuracy,
+                         evaluate_semantic_miou, get_gt_bbox, get_gt_instances)
+
+
+def save_checkpoint(path, model, optimizer, epoch, global_step):
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save({"epoch": epoch, "global_step": global_step, "state_dict": model.state_dict(),
+                "optimizer_states": [optimizer.state_dict()] if optimizer is not None else []}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, strict=True):
+    """-> (epoch, global_step) stored in the file; accepts Lightning checkpoints and bare state_dicts"""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    state = ck.get("state_dict", ck)
+    own = model.state_dict()
+    fixed = {}
+    for k, v in state.items():
+        if k in own and own[k].shape != v.shape and own[k].numel() == v.numel():
+            v = v.reshape(own[k].shape)          # e.g. a kernel_size-1 convolution stored as [Cin, Cout]
+        fixed[k] = v
+    model.load_state_dict(fixed, strict=strict)
+    if optimizer is not None and ck.get("optimizer_states"):
+        optimizer.load_state_dict(ck["optimizer_states"][0])
+    return int(ck.get("epoch", -1)), int(ck.get("global_step", 0))
+
+
+def predicted_instances(model, data_dict, output_dict):
+    """the per-model argument plumbing of the reference's validation steps (pointgroup.py:136-148, hais.py:152-161,
+    softgroup.py:212-219); tensors stay on the device"""
+    cfg = model.hparams.cfg
+    scan_id, xyz, n_ign = data_dict["scan_ids"][0], data_dict["point_xyz"], len(cfg.data.ignore_classes)
+    name = type(model).__name__
+    if name == "PointGroup":
+        scores, idx, off = output_dict["proposal_scores"]
+        return model._get_pred_instances(scan_id, xyz, scores, idx, off.size(0) - 1, output_dict["semantic_scores"], n_ign)
+    if name == "HAIS":
+        scores, idx, off, mask_scores = output_dict["proposal_scores"]
+        return model._get_pred_instances(scan_id, xyz, scores, idx, off.size(0) - 1, mask_scores,
+                                         output_dict["semantic_scores"], n_ign)
+    if "cls_scores" not in output_dict:          # no proposal survived the grouping
+        return []
+    return model._get_pred_instances(scan_id, xyz, output_dict["proposals_idx"], output_dict["semantic_scores"].size(0),
+                                     output_dict["cls_scores"], output_dict["iou_scores"], output_dict["mask_scores"], n_ign)
+
+
+class Trainer:
+    def __init__(self, cfg, model, datamodule, out_dir=None, log=print):
+        self.cfg, self.model, self.dm, self.log = cfg, model, datamodule, log
+        self.out_dir = out_dir or os.path.join(cfg.exp_output_root_path, "training")
+        self.optimizer = model.configure_optimizers()
+        self.global_step = 0
+        self.history = []
+
+    def validate(self):
+        model, cfg = self.model, self.cfg
+        model.eval()
+        losses, acc, miou, preds, gts, boxes = [], [], [], [], [], []
+        with torch.no_grad():
+            for batch in self.dm.val_dataloader():
+                out = model(batch)
+                losses.append(float(sum(model._loss(batch, out).values())))
+                sem_pred = out["semantic_scores"].max(1)[1]
+                acc.append(evaluate_semantic_accuracy(sem_pred, batch["sem_labels"], ignore_label=-1))
+                miou.append(evaluate_semantic_miou(sem_pred, batch["sem_labels"], ignore_label=-1))
+                if model.current_epoch > cfg.model.network.prepare_epochs:
+                    inst = predicted_instances(model, batch, out)
+                    if inst:
+                        xyz = batch["point_xyz"].cpu().numpy()
+                        ids = batch["instance_ids"].cpu()
+                        sem = batch["sem_labels"].cpu()
+                        preds.append(inst)
+                        boxes.append(get_gt_bbox(xyz, ids.numpy(), sem.numpy(), -1, cfg.data.ignore_classes))
+                        gts.append(get_gt_instances(sem.clone(), ids.clone(), cfg.data.ignore_classes))
+        res = {"val/total_loss": float(np.mean(losses)), "val_eval/semantic_accuracy": float(np.mean(acc)),
+               "val_eval/semantic_mean_iou": float(np.mean(miou))}
+        if preds:
+            ev = GeneralDatasetEvaluator(cfg.data.class_names, -1, cfg.data.ignore_classes)
+            r = ev.evaluate(preds, gts, print_result=False)
+            res.update({"val_eval/AP": float(r["all_ap"]), "val_eval/AP 50%": float(r["all_ap_50%"]),
+                        "val_eval/AP 25%": float(r["all_ap_25%"])})
+            with np.errstate(invalid="ignore"):
+                b = evaluate_bbox_acc(preds, boxes, cfg.data.class_names, cfg.data.ignore_classes, print_result=False)
+            res.update({"val_eval/BBox AP 25%": float(b["all_bbox_ap_0.25"]["avg"]),
+                        "val_eval/BBox AP 50%": float(b["all_bbox_ap_0.5"]["avg"])})
+        model.train()
+        return res
+
+    def fit(self, max_epochs=None, ckpt_path=None):
+        cfg, model, opt = self.cfg, self.model, self.optimizer
+        max_epochs = max_epochs or cfg.model.trainer.max_epochs
+        every = cfg.model.trainer.check_val_every_n_epoch
+        start = 0
+        if ckpt_path:
+            epoch, self.global_step = load_checkpoint(ckpt_path, model, opt)
+            start = epoch + 1
+            model.current_epoch = epoch
+            model.on_train_epoch_end(opt)          # the decayed rate of the epoch that was just finished
+        model.train()
+        for epoch in range(start, max_epochs):
+            model.current_epoch = epoch
+            total, n = 0.0, 0
+            for batch in self.dm.train_dataloader():
+                opt.zero_grad(set_to_none=True)
+                loss = model.training_step(batch)
+                loss.backward()
+                opt.step()
+                self.global_step += 1
+                total += float(loss.detach())
+                n += 1
+            model.on_train_epoch_end(opt)
+            rec = {"epoch": epoch, "train/total_loss": total / max(n, 1), "lr": opt.param_groups[0]["lr"]}
+            if (epoch + 1) % every == 0:
+                rec.update(self.validate())
+                save_checkpoint(os.path.join(self.out_dir, f"epoch={epoch}.ckpt"), model, opt, epoch, self.global_step)
+            self.history.append(rec)
+            self.log(rec)
+        return self.history
