@@ -79,6 +79,15 @@ class MinkowskiBatchNorm(nn.Module):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
+        # `num_batches_tracked += 1` is one tiny launch per BatchNorm per step (80 per step in the backbone); the
+        # count is kept on the host and added to the buffer whenever somebody reads it (state_dict / checkpoint)
+        self._pending_batches = 0
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_batches_tracked())
+
+    def flush_batches_tracked(self):
+        if self._pending_batches and self.bn.num_batches_tracked is not None:
+            self.bn.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
 
     def forward(self, x: SparseTensor):
         bn = self.bn
@@ -98,7 +107,7 @@ class MinkowskiBatchNorm(nn.Module):
                 else:
                     mean, invstd, scale, shift = get_backend().bn_stats(feats.detach(), bn.eps, mom, g, b, rm, rv)
                 if rm is not None:
-                    bn.num_batches_tracked += 1
+                    self._pending_batches += 1
         else:
             with torch.no_grad():
                 invstd = torch.rsqrt(bn.running_var + bn.eps)

@@ -141,7 +141,16 @@ __global__ void bfs_flatten_kernel(int N, int *parent, int *root, int *comp_size
     if (i >= N) return;
     const int r = uf_find(parent, i);
     root[i] = r;
-    atomicAdd(&comp_size[r], 1);
+    // wave-aggregated count: neighbouring points mostly share a root, one atomic per distinct root of the wave
+    // (one atomic per point on a few hot counters took 230 us for 575k points)
+    unsigned long long todo = __ballot(1);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r0 = __shfl(r, leader, 64);
+        const unsigned long long same = __ballot(r == r0) & todo;
+        if (lane_id() == leader) atomicAdd(&comp_size[r0], __popcll(same));
+        todo &= ~same;
+    }
     // a list cut at the cap makes the graph directed (bfs_cluster.cu:38-43): only then can a weak component
     // hold more than one cluster, and only then is the order-by-replay kernel required
     if (start_len[i * 2 + 1] >= 1000 && counters[5] == 0) atomicOr(&counters[5], 1);
