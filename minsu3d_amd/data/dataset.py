@@ -85,55 +85,60 @@ class GeneralDataset(Dataset):
         noise = np.stack(T.elastic_noise(x, gran))          # same random draws as the host path
         return self.elastic_fn(x, noise, gran, mag)
 
+    # ---- the stages of a sample, in the reference's order of random draws (general_dataset.py:96-150)
+    def _augment(self, xyz, normals, colors):
+        m = self._get_augmentation_matrix()
+        xyz = np.matmul(xyz, m)
+        normals = np.matmul(normals, np.linalg.inv(m).T)
+        if self.cfg.data.augmentation.jitter_rgb:
+            colors = colors + np.random.randn(3) * 0.1
+        return xyz, normals, colors.astype(np.float32)
+
+    def _voxel_units(self, xyz, train):
+        """metric -> voxel units, two elastic distortions when training (coarse 6/40, fine 20/160 at 2 cm), shifted
+        into the positive octant"""
+        per_metre = 1 / self.cfg.data.voxel_size
+        v = xyz * per_metre
+        if train and self.cfg.data.augmentation.elastic:
+            for gran, mag in ((6 * per_metre // 50, 40 * per_metre / 50), (20 * per_metre // 50, 160 * per_metre / 50)):
+                v = self._elastic(v, gran, mag)
+        v = np.asarray(v)
+        return v - v.min(axis=0)
+
+    def _crop_window(self, v, sem_labels, instance_ids):
+        """random window of at most max_num_point points that still contains labelled points (up to 20 tries)"""
+        keep = np.ones(v.shape[0], dtype=bool)
+        if keep.shape[0] <= self.max_num_point:
+            return v, keep
+        half, kept = self.max_num_point // 2, 0
+        for _ in range(20):
+            shifted, keep = T.crop(v, self.max_num_point, self.cfg.data.full_scale[1])
+            kept = np.count_nonzero(keep)
+            if kept >= half and np.any(sem_labels[keep] != -1) and np.any(instance_ids[keep] != -1):
+                return shifted, keep
+        if kept < half or np.all(sem_labels[keep] == -1) and np.all(instance_ids[keep] == -1):
+            raise Exception("Over-cropped!")
+        return v, keep
+
     def __getitem__(self, idx):
-        scene = self.scenes[idx]
-        cfg = self.cfg
+        scene, net = self.scenes[idx], self.cfg.model.network
         train = self.split == "train"
-        xyz = scene["xyz"].astype(np.float32)
-        colors = scene["rgb"].astype(np.float32)
-        normals = scene["normal"].astype(np.float32)
-        instance_ids = scene["instance_ids"].astype(np.int16)
-        sem_labels = scene["sem_labels"].astype(np.int16)
+        xyz, colors, normals = (scene[k].astype(np.float32) for k in ("xyz", "rgb", "normal"))
+        instance_ids, sem_labels = scene["instance_ids"].astype(np.int16), scene["sem_labels"].astype(np.int16)
         if train:
-            m = self._get_augmentation_matrix()
-            xyz = np.matmul(xyz, m)
-            normals = np.matmul(normals, np.transpose(np.linalg.inv(m)))
-            if cfg.data.augmentation.jitter_rgb:
-                colors += np.random.randn(3) * 0.1
-        scale = 1 / cfg.data.voxel_size
-        if train and cfg.data.augmentation.elastic:
-            e = self._elastic(xyz * scale, 6 * scale // 50, 40 * scale / 50)
-            e = self._elastic(e, 20 * scale // 50, 160 * scale / 50)
-        else:
-            e = xyz * scale
-        e = np.asarray(e)
-        e = e - e.min(axis=0)
+            xyz, normals, colors = self._augment(xyz, normals, colors)
+        v = self._voxel_units(xyz, train)
         if train:
-            valid = np.ones(xyz.shape[0], dtype=bool)
-            if valid.shape[0] > self.max_num_point:                              # :127-140
-                count = 0
-                for _ in range(20):
-                    tmp, valid = T.crop(e, self.max_num_point, cfg.data.full_scale[1])
-                    count = np.count_nonzero(valid)
-                    if count >= self.max_num_point // 2 and np.any(sem_labels[valid] != -1) \
-                            and np.any(instance_ids[valid] != -1):
-                        e = tmp
-                        break
-                if count < self.max_num_point // 2 or np.all(sem_labels[valid] == -1) \
-                        and np.all(instance_ids[valid] == -1):
-                    raise Exception("Over-cropped!")
-            e, xyz, normals, colors, sem_labels = e[valid], xyz[valid], normals[valid], colors[valid], sem_labels[valid]
-            instance_ids = self._get_cropped_inst_ids(instance_ids, valid)
-        e = e / scale
+            v, keep = self._crop_window(v, sem_labels, instance_ids)
+            v, xyz, normals, colors, sem_labels = v[keep], xyz[keep], normals[keep], colors[keep], sem_labels[keep]
+            instance_ids = self._get_cropped_inst_ids(instance_ids, keep)
         num_instance, centers, npoint, inst_cls = self._get_inst_info(xyz, instance_ids, sem_labels)
-        feats = [colors] if cfg.model.network.use_color else []
-        if cfg.model.network.use_normal:
-            feats.append(normals)
-        feats.append(xyz)
-        return {"scan_id": self.scene_names[idx], "point_xyz": xyz, "sem_labels": sem_labels, "instance_ids": instance_ids,
-                "num_instance": np.array(num_instance, dtype=np.int32), "instance_center_xyz": centers,
-                "instance_num_point": np.array(npoint, dtype=np.int32), "instance_semantic_cls": inst_cls,
-                "point_xyz_elastic": e, "point_features": np.concatenate(feats, axis=1).astype(np.float32)}
+        channels = ([colors] if net.use_color else []) + ([normals] if net.use_normal else []) + [xyz]
+        return dict(scan_id=self.scene_names[idx], point_xyz=xyz, sem_labels=sem_labels, instance_ids=instance_ids,
+                    num_instance=np.array(num_instance, dtype=np.int32), instance_center_xyz=centers,
+                    instance_num_point=np.array(npoint, dtype=np.int32), instance_semantic_cls=inst_cls,
+                    point_xyz_elastic=v / (1 / self.cfg.data.voxel_size),      # the reference's arithmetic (:143)
+                    point_features=np.concatenate(channels, axis=1).astype(np.float32))
 
 
 ScanNetv2 = GeneralDataset       # the reference selects the class by cfg.data.dataset (data/dataset/__init__.py)
