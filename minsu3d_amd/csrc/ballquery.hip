@@ -157,8 +157,13 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
         for (int w = l; w < bitmap_words; w += 64) s_bits[w] = 0u;
         __builtin_amdgcn_wave_barrier();
     }
-    for (int i = blockIdx.x * waves + wave_id(); i < n; i += gridDim.x * waves) {
-        const float ox = xyz[i * 3 + 0], oy = xyz[i * 3 + 1], oz = xyz[i * 3 + 2];
+    // queries are taken in CELL order (the cell-sorted copy carries the original index): the waves of a workgroup and
+    // of neighbouring workgroups then sweep the same 27 cells back to back and find them in L1/L2, while in input
+    // order (a scan permutes its points) every query streamed its ~2000 candidates from L2
+    for (int sp = blockIdx.x * waves + wave_id(); sp < n; sp += gridDim.x * waves) {
+        const float4 me = cell_pts[sp];
+        const int i = __float_as_int(me.w);
+        const float ox = me.x, oy = me.y, oz = me.z;
         const int b = batch_idxs[i];
         const int total = gather_cells(b, cell_coord(ox, inv_cell), cell_coord(oy, inv_cell), cell_coord(oz, inv_cell),
                                        keys, cell_start, cell_count, mask, s_prefix, s_start);

@@ -448,16 +448,19 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         const int row0 = tile * CR;
         const int b_begin = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile]);
         const int b_end = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile + 1]);
+        const int2 *__restrict__ tile_entries = entries + (size_t)b_begin * 16;
         for (int b0 = b_begin; b0 < b_end; b0 += CBU) {
             int2 ent[CBU];
             f32x4 a[CBU][NCH];
 #pragma unroll
-            for (int u = 0; u < CBU; u++) ent[u] = entries[(size_t)min(b0 + u, b_end - 1) * 16 + jl];
+            for (int u = 0; u < CBU; u++) ent[u] = tile_entries[(unsigned)((min(b0 + u, b_end - 1) - b_begin) * 16 + jl)];
 #pragma unroll
             for (int u = 0; u < CBU; u++) {
-                const float *row = p.in + (size_t)ent[u].x * p.Cin + 4 * q;
+                // wave-uniform base + 32-bit lane offset (Vin * Cin < 2^32 elements is checked by the launcher): the 64-bit
+                // per-lane address arithmetic was a third of the loop's vector instructions
+                const unsigned off = (unsigned)ent[u].x * (unsigned)(NCH * 16) + 4u * (unsigned)q;
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) a[u][ch] = *reinterpret_cast<const f32x4 *>(row + 16 * ch);
+                for (int ch = 0; ch < NCH; ch++) a[u][ch] = *reinterpret_cast<const f32x4 *>(p.in + off + 16 * ch);
             }
             if (p.pre_scale) {
 #pragma unroll
@@ -1145,8 +1148,9 @@ int pairlist_min_rows()
 }
 bool pairlist_shape_ok(int Vout, int K, int Cin, int Cout)
 {
-    return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0 &&
-           Cin <= 32 && Cout <= 32;
+    // Vout <= 2^22: the kernel addresses input rows with 32-bit element offsets (Vin <= 8 * Vout for a stride-2 map)
+    return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && Vout <= (1 << 22) && K > 1 && K <= 27 &&
+           Cin % 16 == 0 && Cout % 16 == 0 && Cin <= 32 && Cout <= 32;
 }
 constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
