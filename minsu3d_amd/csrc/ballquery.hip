@@ -188,12 +188,21 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
         int wlo = 0x7fffffff, whi = -1;  // bitmap words touched by this query (bitmap path only)
         // four 64-candidate slices per trip: the four L2 loads of a lane are issued together (one dependent load per
         // trip made this loop latency-bound: ~1000 cycles per 64 candidates), then consumed in candidate order
+        // candidate t lives in the cell `cur` with prefix[cur] <= t < prefix[cur + 1]; a lane's t only grows, so it keeps
+        // (cell end, position offset) in registers and walks forward instead of bisecting the prefix table in LDS for
+        // every candidate (5 dependent LDS reads each -- the sweep was bound by them, not by the candidate loads)
+        int cur = 0, cur_end = s_prefix[1], cur_off = s_start[0] - s_prefix[0];
         for (int t0 = 0; t0 < total; t0 += 256) {
             float4 p[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int t = t0 + 64 * u + l;
-                p[u] = cell_pts[candidate_pos(min(t, total - 1), s_prefix, s_start)];
+                const int t = min(t0 + 64 * u + l, total - 1);
+                while (t >= cur_end) {  // empty cells are skipped here as well; at most 26 steps per query
+                    cur++;
+                    cur_end = s_prefix[cur + 1];
+                    cur_off = s_start[cur] - s_prefix[cur];
+                }
+                p[u] = cell_pts[cur_off + t];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -243,9 +252,18 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
                 const int w = w0 + l;
                 unsigned bits = (w < w_end) ? s_bits[w] : 0u;
                 if (__ballot(bits != 0u) == 0ull) continue;
+                // exclusive prefix of the per-lane popcounts by bit planes: a word rarely holds more than 1-3 hits, so two
+                // ballots replace the 6-step shuffle scan + 6-step shuffle sum (the scan of the scene-wide bitmap is what
+                // the fill pass of a dense query spends its time on)
                 const int pc = __popc(bits);
-                int rank = emitted + wave_incl_scan(pc) - pc;
-                emitted += wave_sum(pc);
+                int rank = emitted;
+                for (int plane = 0;; plane++) {
+                    const unsigned long long rest = __ballot((pc >> plane) != 0);
+                    if (rest == 0ull) break;
+                    const unsigned long long m1 = __ballot((pc >> plane) & 1);
+                    rank += ballot_rank(m1) << plane;
+                    emitted += __popcll(m1) << plane;
+                }
                 while (bits) {
                     const int bit = __ffs(bits) - 1;
                     bits &= bits - 1;
