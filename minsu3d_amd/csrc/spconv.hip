@@ -170,10 +170,14 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 const int keep = ~(idx[u] >> 31);  // absent neighbour (idx < 0) contributes nothing
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
-                if (!any[u]) continue;
+                // DIRECT (small levels): no skip -- a uniform branch in front of the B-fragment loads makes the compiler
+                // issue them inside the branch and wait on the spot: one L2 round trip per offset, 63 in a row on a
+                // 112-channel level (34 us for 112 rows).  Straight-line code lets the loads of all offsets go out together.
+                if (!DIRECT && !any[u]) continue;
                 if (DIRECT) {
                     // small levels: B fragments straight from the global image (L2 resident), no LDS staging
-                    const float *w = p.wf + ((size_t)(((g0 + u) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+                    // offsets past K (last group) multiply zeros: clamp the read to the last real offset's image
+                    const float *w = p.wf + ((size_t)((min(g0 + u, p.K - 1) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
 #pragma unroll
