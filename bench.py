@@ -129,6 +129,7 @@ def main():
     if not args.no_roofline:
         timer = ms_backend.KernelTimer(lambda name, K, cin, cout: name == "spconv_fwd" and K == 27 and cin == 16 and cout == 16,
                                        be.lib)
+        timer.min_rows = 50_000 * args.batch      # the backbone's full-resolution level, not the proposal grids of the ScoreNet
         be.kernel_timer = timer
 
     def sync_all():
@@ -177,7 +178,7 @@ def main():
                         traffic = int(json.load(f)["traffic_bytes_per_launch"])
                 line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                    "kernel": "spconv_fwd_pairlist_kernel<1,1> (3x3x3 16->16 pair-list gather/MFMA at full resolution, forward launches)",
+                                    "kernel": "spconv_fwd_pairlist_kernel<1,1> (3x3x3 16->16 pair-list gather/MFMA at full resolution, forward and backward-data launches)",
                                     "launches": s["launches"], "avg_us": round(s["avg_ms"] * 1e3, 2),
                                     "algorithmic_bytes_per_launch": int(s["avg_bytes"])}
         if world == 1 and not args.no_cpu_baseline:

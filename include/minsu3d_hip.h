@@ -218,6 +218,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                int need_dx, float *dx, float *dgb, float *dW, float *ws,
                                const int *ol_fwd_kt_start /* offset list of nbr_fwd or NULL */, const int *ol_fwd_entries,
                                const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
+                               void *ev_start /* hipEvent_t or NULL: around the backward-data kernel */, void *ev_stop,
                                ms3d_stream_t stream);
 
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */

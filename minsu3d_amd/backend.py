@@ -253,6 +253,7 @@ class KernelTimer:
     (SURVEY 8d formula with the table's real pair count)."""
 
     def __init__(self, select, lib, max_records=112):
+        self.min_rows = 0               # only tables with at least this many output rows (full-resolution level)
         self.max_records = max_records  # sampling: event create/record per launch is host time inside the timed region
         self.select = select            # (name, K, cin, cout) -> bool
         self.lib = lib
@@ -263,12 +264,13 @@ class KernelTimer:
         self.enabled = False
 
     def begin(self, name, K, cin, cout, nbr):
-        if not self.enabled or len(self.records) >= self.max_records or not self.select(name, K, cin, cout):
+        if not self.enabled or len(self.records) >= self.max_records or not self.select(name, K, cin, cout) \
+                or nbr.shape[1] < self.min_rows:
             return None
-        key = (nbr.data_ptr(), nbr.numel())
-        if key not in self._pairs:
-            self._pairs[key] = int((nbr >= 0).sum().item())
-        nM = self._pairs[key]
+        nM = getattr(nbr, "_ms3d_pairs", None)      # cached on the table object (an address can be reused by another table)
+        if nM is None:
+            nM = int((nbr >= 0).sum().item())
+            nbr._ms3d_pairs = nM
         nbytes = nM * (cin + cout) * 4 + nM * 8 + K * cin * cout * 4
         ev = (C.c_void_p(self.lib.ms3d_event_create()), C.c_void_p(self.lib.ms3d_event_create()), nbytes)
         self.records.append(ev)
@@ -525,13 +527,16 @@ class _HipEngine:
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
         plf = self.offsetlist(nbr_fwd, K, vout)
         plb = self.pairlist(nbr_bwd, K, vin) if want_dx else (None, None)
+        timer = self.kernel_timer
+        tok = timer.begin("spconv_fwd", K, cout, cin, nbr_bwd) if (timer is not None and want_dx) else None
+        ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
         _lib.check(self.lib.ms3d_spconv_layer_backward(
             _lib.ptr(x), _lib.ptr(dy), _lib.ptr(wf_buf), _lib.ptr(nbr_fwd), _lib.ptr(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _lib.ptr(bn["scale"] if has_bn else None), _lib.ptr(bn["shift"] if has_bn else None),
             _lib.ptr(bn["mean"] if has_bn else None), _lib.ptr(bn["invstd"] if has_bn else None),
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _lib.ptr(dx),
             _lib.ptr(dgb), _lib.ptr(dW), _lib.ptr(ws), _lib.ptr(plf[0]), _lib.ptr(plf[1]), _lib.ptr(plb[0]),
-            _lib.ptr(plb[1]), _lib.stream_handle()), "ms3d_spconv_layer_backward")
+            _lib.ptr(plb[1]), ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_backward")
         return (dx if need_dx else None), dgb, dW
 
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):

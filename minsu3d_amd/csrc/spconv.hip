@@ -447,6 +447,14 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};  // per-lane column sums (columns 4*(l % F4)..+3)
     const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
     const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
+    // fused input BatchNorm(+ReLU): this lane's 4 channels per chunk, loaded once (inside the batch loop the two loads
+    // were re-issued and waited for in every chunk)
+    f32x4 pre_sc[NCH], pre_sh[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        pre_sc[ch] = p.pre_scale ? *reinterpret_cast<const f32x4 *>(p.pre_scale + 16 * ch + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        pre_sh[ch] = p.pre_scale ? *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int tile = t_begin; tile < t_end; tile++) {
         const int row0 = tile * CR;
@@ -469,8 +477,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
             if (p.pre_scale) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.pre_scale + 16 * ch + 4 * q);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q);
+                    const f32x4 sc = pre_sc[ch], sh = pre_sh[ch];
 #pragma unroll
                     for (int u = 0; u < CBU; u++)
 #pragma unroll

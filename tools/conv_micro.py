@@ -43,3 +43,16 @@ us_w = e0.elapsed_time(e1) / n * 1e3
 alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
 print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | wgrad {us_w:.1f} us"
       f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
+# layer-style launch (fused BN+ReLU prologue, residual, output statistics) timed by the in-library HIP events
+from minsu3d_amd.backend import KernelTimer
+tm = KernelTimer(lambda *a: True, be.lib, max_records=40); be.kernel_timer = tm
+scale = torch.rand(cin, device=dev) + 0.5; shift = torch.randn(cin, device=dev) * 0.1
+res = torch.randn(vout, cout, device=dev) if cin == cout else None
+for _ in range(3):
+    be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, res, None, True)
+tm.enabled = True
+for _ in range(20):
+    be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, res, None, True)
+torch.cuda.synchronize()
+s = tm.summary()
+print(f"layer forward (BN+ReLU prologue, residual, stats): events avg {s['avg_ms'] * 1e3:.1f} us over {s['launches']} launches")
