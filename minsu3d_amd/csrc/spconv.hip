@@ -1525,16 +1525,20 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
                                int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *ol_fwd_kt_start,
                                const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
-                               ms3d_stream_t stream)
+                               void *ev_start, void *ev_stop, ms3d_stream_t stream)
 {
     const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     const bool bn = scale != nullptr;
     int rc;
+    // optional HIP events bracketing ONLY the backward-data convolution kernel (bench.py roofline)
+    if (ev_start && (need_dx || bn)) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     if (need_dx || bn) {
         if (!bn) {
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
             if (rc) return rc;
+            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+            ev_stop = nullptr;
         } else {
             if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
             const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, pl_bwd_tile_start && pl_bwd_entries);
@@ -1542,6 +1546,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
                                      mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
             if (rc) return rc;
+            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+            ev_stop = nullptr;
             rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
             if (rc) return rc;
             if (need_dx) {
