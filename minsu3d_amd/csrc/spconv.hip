@@ -1148,7 +1148,7 @@ struct FwdGeom {
     size_t lds;
     bool ok, small, pairlist;
 };
-constexpr int PAIRLIST_MIN_ROWS = 50000;  // below this the 16-row kernels win (weight staging per block dominates)
+constexpr int PAIRLIST_MIN_ROWS = 30000;  // below this the 16-row kernels win (weight staging per block dominates)
 int pairlist_min_rows()
 {
     static const int v = [] {
@@ -1350,7 +1350,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     p.in = in; p.dout = dout; p.nbr = nbr; p.partial = partial_ws; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = ms3d_divup(Cout, 16); p.pre_relu = pre_relu;
     const int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
-    const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 2 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
+    const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
     const int gran = use_list ? MS3D_PL_ROWS : 16;
     p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), gran) * gran;
@@ -1359,7 +1359,10 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     if (nb > 14) return MS3D_E_UNSUPPORTED;
     int rc;
     if (use_list) {
-        rc = nb == 1 ? launch_wgrad_offsetlist<1>(p, nblk, stream) : launch_wgrad_offsetlist<2>(p, nblk, stream);
+        rc = nb == 1 ? launch_wgrad_offsetlist<1>(p, nblk, stream)
+           : nb == 2 ? launch_wgrad_offsetlist<2>(p, nblk, stream)
+           : nb == 3 ? launch_wgrad_offsetlist<3>(p, nblk, stream)
+                     : launch_wgrad_offsetlist<4>(p, nblk, stream);
         if (rc) return rc;
         wgrad_reduce_kernel<<<ms3d_divup(n, 16), 256, 0, stream>>>(partial_ws, nblk, n, dW);
         MS3D_LAUNCH_CHECK();
