@@ -53,7 +53,16 @@ class MinkowskiConvolution(_ConvBase):
             out_ts = ts
         else:
             raise NotImplementedError((self.kernel_size, self.stride))
-        y, stats = Fn.conv(x._F, self.kernel, spec, x._pending,
+        feats, kernel, pending = x._F, self.kernel, x._pending
+        if cin % 16 != 0 and cin < 16 and self.kernel_volume > 1 and pending is None and spec.vout >= 30000:
+            # the network's input convolution (6 channels) at full resolution: zero-padding rows and weights to one
+            # 16-channel chunk lets it take the aligned pair-list kernels (16-byte row gathers) instead of the
+            # scalar-load table walk; the padded weight rows see zeros, autograd slices their gradient away
+            pad = 16 - cin
+            feats = torch.nn.functional.pad(feats, (0, pad))
+            kernel = torch.nn.functional.pad(kernel, (0, 0, 0, pad))
+            spec = Fn.ConvSpec(spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout, spec.K, 16, cout, spec.mirror)
+        y, stats = Fn.conv(feats, kernel, spec, pending,
                            residual=None if residual is None else residual._raw(), want_stats=self.training)
         return x._like(y, tensor_stride=out_ts, stats=stats)
 
