@@ -933,7 +933,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(const float *__
                                                                 float *__restrict__ invstd_out, float *__restrict__ scale_out,
                                                                 float *__restrict__ shift_out)
 {
-    __shared__ double s_1[64][17], s_2[64][17];
+    __shared__ double s_1[16][17], s_2[16][17];
     const int cl = threadIdx.x & 15, lp = threadIdx.x >> 4;  // 16 columns x 64 part lanes
     const int c = blockIdx.x * 16 + cl;
     double a1 = 0.0, a2 = 0.0;
@@ -958,12 +958,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(const float *__
             a2 += (double)partial[((size_t)p * 2 + 1) * C + c];
         }
     }
-    s_1[lp][cl] = a1;
-    s_2[lp][cl] = a2;
+    // the 4 part lanes of a wave are folded with shuffles (fixed order), then 16 wave rows go through LDS
+    a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+    a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+    if ((threadIdx.x & 63) < 16) {
+        s_1[threadIdx.x >> 6][cl] = a1;
+        s_2[threadIdx.x >> 6][cl] = a2;
+    }
     __syncthreads();
     if (threadIdx.x >= 16 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < 64; i++) {  // fixed order -> deterministic
+#pragma unroll
+    for (int i = 0; i < 16; i++) {  // fixed order -> deterministic
         s1 += s_1[i][cl];
         s2 += s_2[i][cl];
     }
@@ -1087,16 +1093,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
 __global__ __launch_bounds__(1024) void reduce_partial_kernel(const float *__restrict__ partial, int nparts, int n,
                                                               float *__restrict__ out)
 {
-    __shared__ double s_sum[64][17];
+    __shared__ double s_sum[16][17];
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), lane_p = threadIdx.x >> 4;
     double s = 0.0;
     if (col < n)
         for (int p = lane_p; p < nparts; p += 64) s += (double)partial[(size_t)p * n + col];
-    s_sum[lane_p][threadIdx.x & 15] = s;
+    // fold the 4 part lanes of a wave with shuffles, then 16 wave rows through LDS (fixed order)
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((threadIdx.x & 63) < 16) s_sum[threadIdx.x >> 6][threadIdx.x & 15] = s;
     __syncthreads();
     if (threadIdx.x < 16 && col < n) {
         double t = 0.0;
-        for (int i = 0; i < 64; i++) t += s_sum[i][threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t += s_sum[i][threadIdx.x];
         out[col] = (float)t;
     }
 }
