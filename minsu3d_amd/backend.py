@@ -488,20 +488,30 @@ class _HipEngine:
         return pick[:int(n_pick.item())]
 
     # ---- one library call per layer and direction (used by MinkowskiEngine/functional.py)
+    def _geom(self, what, *key):
+        """launch-geometry queries of the library, memoised (three ctypes calls per layer otherwise)"""
+        cache = self.__dict__.setdefault("_geom_cache", {})
+        k = (what,) + key
+        v = cache.get(k)
+        if v is None:
+            fn = getattr(self.lib, what)
+            if what in ("ms3d_spconv_wf_floats", "ms3d_spconv_layer_ws_floats"):
+                fn.restype = C.c_size_t
+            v = cache[k] = fn(*[int(a) for a in key])
+        return v
+
     def conv_layer_forward(self, x, W3, nbr_fwd, vout, K, cin, cout, mirror_bwd, pre, pre_relu, residual, bias,
                            want_stats):
         """-> (y, stats or None, wf_buf) ; wf_buf carries both weight images to the backward call"""
         x = self._dev(x)
         dev = x.device
-        self.lib.ms3d_spconv_wf_floats.restype = C.c_size_t
-        nwf = self.lib.ms3d_spconv_wf_floats(int(K), int(cin), int(cout)) + \
-            self.lib.ms3d_spconv_wf_floats(int(K), int(cout), int(cin))
+        nwf = self._geom("ms3d_spconv_wf_floats", K, cin, cout) + self._geom("ms3d_spconv_wf_floats", K, cout, cin)
         wf_buf = torch.empty(nwf, dtype=torch.float32, device=dev)
         y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
         stats = None
         pl = self.pairlist(nbr_fwd, K, vout)
         if want_stats:
-            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), int(pl[0] is not None))
+            nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, int(pl[0] is not None))
             stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev)
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
@@ -518,8 +528,7 @@ class _HipEngine:
         """-> (dx or None, dgb [2,cin] = (dbeta, dgamma) or None, dW [K,cin,cout])"""
         x = self._dev(x); dy = self._dev(dy)
         dev = x.device
-        self.lib.ms3d_spconv_layer_ws_floats.restype = C.c_size_t
-        ws = self.ws.get("layer", 4 * self.lib.ms3d_spconv_layer_ws_floats(int(vin), int(vout), int(K), int(cin), int(cout)), dev)
+        ws = self.ws.get("layer", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
         has_bn = bn is not None
         want_dx = need_dx or has_bn
         dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
