@@ -745,16 +745,20 @@ int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 // per sub-chunk), 4 instead of 2 batches per trip (60 us).
 constexpr int WGRAD_TB = 2;  // 16-pair batches per trip
 
-template <int NBT>
+// NCH = 16-channel input chunks handled by one workgroup (blockIdx.z selects the group): the entries and the dout rows
+// of a batch are fetched once for all of them instead of once per chunk.
+template <int NBT, int NCH>
 __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs p)
 {
     constexpr int TB = WGRAD_TB;
+    constexpr int NT = NCH + NBT;   // 16x16 tiles parked per batch
+    constexpr int NA = NCH * NBT;   // accumulators
     extern __shared__ float lds[];
     __shared__ int s_lo[32], s_cum[33], s_pk[16][2];
     const int l = lane_id(), q = l >> 4, cl = l & 15;
     const int nw = blockDim.x >> 6, w = wave_id();
-    float *s_part = lds;                                                   // [nw][2][NBT*256]
-    float *s_tile = lds + (size_t)nw * 2 * NBT * 256 + (size_t)w * TB * (1 + NBT) * 256;  // [TB][1 + NBT][16 pairs][16]
+    float *s_part = lds;                                                          // [nw][2][NA*256]
+    float *s_tile = lds + (size_t)nw * 2 * NA * 256 + (size_t)w * TB * NT * 256;  // [TB][NCH + NBT][16 pairs][16]
     const int tiles = (p.Vout + MS3D_PL_ROWS - 1) / MS3D_PL_ROWS;
     const int tpb = p.rows_per_block / MS3D_PL_ROWS;  // rows_per_block is a multiple of the tile size here
     const int t_lo = min(tiles, (int)blockIdx.x * tpb), t_hi = min(tiles, t_lo + tpb);
@@ -772,16 +776,31 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     if (threadIdx.x < 32) s_pk[threadIdx.x >> 1][threadIdx.x & 1] = -1;
     __syncthreads();
 
-    const int c0 = blockIdx.z * 16 + 4 * q;  // first of the 4 input channels this lane fetches
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.pre_scale) {
-        sc = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
-        sh = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
+    const int cbase = blockIdx.z * NCH * 16;  // first input channel of this workgroup
+    f32x4 sc[NCH], sh[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const int c0 = cbase + 16 * ch + 4 * q;
+        const bool ok = p.pre_scale && c0 < p.Cin;
+        sc[ch] = ok ? *reinterpret_cast<const f32x4 *>(p.pre_scale + c0) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        sh[ch] = ok ? *reinterpret_cast<const f32x4 *>(p.pre_shift + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.ol_entries);
     float *slab = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
+    // D layout: row (input channel within its chunk) = 4q + reg, column (output channel) = cl
+    auto store_slab = [&](int k, const f32x4 (&acc)[NA]) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ci = cbase + 16 * ch + 4 * q + r, j = 16 * nb + cl;
+                    if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[ch * NBT + nb][r];
+                }
+    };
 
     const int T = s_cum[p.K];
     const int s0 = (int)((long long)T * w / nw), s1 = (int)((long long)T * (w + 1) / nw);
@@ -792,13 +811,13 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
         if (g_lo >= g_hi) continue;  // wave-uniform
         const int pbase = s_lo[k] - c_lo;  // list position of concatenated index g = pbase + g
         const int p_begin = pbase + g_lo, p_end = pbase + g_hi;
-        f32x4 acc[NBT];
+        f32x4 acc[NA];
 #pragma unroll
-        for (int b = 0; b < NBT; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NA; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // pipeline: entries two trips ahead, row gathers one trip ahead of the MFMAs (`opaque0` keeps the compiler
         // from merging the in-loop loads with the ones in front of the loop, which would undo the prefetch)
         int2 e[TB];
-        f32x4 ga[TB], gb[TB][NBT];
+        f32x4 ga[TB][NCH], gb[TB][NBT];
         auto load_entries = [&](int base) {
 #pragma unroll
             for (int t = 0; t < TB; t++) e[t] = entries[min(base + 16 * t + cl, p_end - 1)];
@@ -806,7 +825,9 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
         auto gather = [&]() {
 #pragma unroll
             for (int t = 0; t < TB; t++) {
-                ga[t] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)e[t].x * p.Cin + c0);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++)
+                    ga[t][ch] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)e[t].x * p.Cin + min(cbase + 16 * ch, p.Cin - 16) + 4 * q);
 #pragma unroll
                 for (int nb = 0; nb < NBT; nb++)
                     gb[t][nb] = *reinterpret_cast<const f32x4 *>(p.dout + (size_t)e[t].y * p.Cout + 16 * nb + 4 * q);
@@ -816,10 +837,11 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
         gather();
         load_entries(p_begin + 16 * TB + opaque0);
         for (int base = p_begin; base < p_end; base += 16 * TB) {
-            f32x4 ca[TB], cb[TB][NBT];
+            f32x4 ca[TB][NCH], cb[TB][NBT];
 #pragma unroll
             for (int t = 0; t < TB; t++) {
-                ca[t] = ga[t];
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) ca[t][ch] = ga[t][ch];
 #pragma unroll
                 for (int nb = 0; nb < NBT; nb++) cb[t][nb] = gb[t][nb];
             }
@@ -829,49 +851,51 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
 #pragma unroll
             for (int t = 0; t < TB; t++) {
                 const bool ok = base + 16 * t + cl < p_end;
+                float *ta = s_tile + (size_t)t * NT * 256;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float v = ca[t][i];
-                    if (p.pre_scale) {
-                        v = fmaf(v, sc[i], sh[i]);
-                        if (p.pre_relu) v = fmaxf(v, 0.f);
+                for (int ch = 0; ch < NCH; ch++) {
+                    const bool ch_ok = ok && cbase + 16 * ch < p.Cin;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float v = ca[t][ch][i];
+                        if (p.pre_scale) {
+                            v = fmaf(v, sc[ch][i], sh[ch][i]);
+                            if (p.pre_relu) v = fmaxf(v, 0.f);
+                        }
+                        ca[t][ch][i] = ch_ok ? v : 0.f;
                     }
-                    ca[t][i] = ok ? v : 0.f;
+                    *reinterpret_cast<f32x4 *>(ta + ch * 256 + cl * 16 + 4 * q) = ca[t][ch];
                 }
-                float *ta = s_tile + (size_t)t * (1 + NBT) * 256;
-                *reinterpret_cast<f32x4 *>(ta + cl * 16 + 4 * q) = ca[t];
 #pragma unroll
-                for (int nb = 0; nb < NBT; nb++) *reinterpret_cast<f32x4 *>(ta + (1 + nb) * 256 + cl * 16 + 4 * q) = cb[t][nb];
+                for (int nb = 0; nb < NBT; nb++)
+                    *reinterpret_cast<f32x4 *>(ta + (NCH + nb) * 256 + cl * 16 + 4 * q) = cb[t][nb];
             }
 #pragma unroll
             for (int t = 0; t < TB; t++) {
-                const float *ta = s_tile + (size_t)t * (1 + NBT) * 256;
+                const float *ta = s_tile + (size_t)t * NT * 256;
 #pragma unroll
                 for (int st = 0; st < 4; st++) {
-                    const float av = ta[(4 * st + q) * 16 + cl];  // A[m = ci cl][k = pair 4st + q]
+                    float bv[NBT];
 #pragma unroll
-                    for (int nb = 0; nb < NBT; nb++) {
-                        const float bv = ta[(1 + nb) * 256 + (4 * st + q) * 16 + cl];  // B[k = pair][n = co cl]
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < NBT; nb++) bv[nb] = ta[(NCH + nb) * 256 + (4 * st + q) * 16 + cl];  // B[k = pair][n = co cl]
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) {
+                        const float av = ta[ch * 256 + (4 * st + q) * 16 + cl];  // A[m = ci cl][k = pair 4st + q]
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++)
+                            acc[ch * NBT + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[ch * NBT + nb], 0, 0, 0);
                     }
                 }
             }
         }
-        // D layout: row (input channel within the chunk) = 4q + reg, column (output channel) = cl
         if (g_lo == c_lo && g_hi == c_hi) {
-#pragma unroll
-            for (int nb = 0; nb < NBT; nb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
-                    if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[nb][r];
-                }
+            store_slab(k, acc);
         } else {
-            float *dst = s_part + (size_t)(w * 2 + n_partial) * NBT * 256;
+            float *dst = s_part + (size_t)(w * 2 + n_partial) * NA * 256;
 #pragma unroll
-            for (int nb = 0; nb < NBT; nb++)
+            for (int b = 0; b < NA; b++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst[nb * 256 + r * 64 + l] = acc[nb][r];
+                for (int r = 0; r < 4; r++) dst[b * 256 + r * 64 + l] = acc[b][r];
             if (l == 0) s_pk[w][n_partial] = k;
             n_partial++;  // at most 2: the offsets cut by the two ends of the slice
         }
@@ -880,45 +904,37 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     // offsets cut by slice boundaries (partials summed in wave order) and offsets without pairs in this chunk (zeros)
     for (int k = w; k < p.K; k += nw) {
         const bool empty = s_cum[k + 1] == s_cum[k];
-        f32x4 acc[NBT];
+        f32x4 acc[NA];
 #pragma unroll
-        for (int b = 0; b < NBT; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NA; b++) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bool any = false;
         for (int ww = 0; ww < nw; ww++)
             for (int jj = 0; jj < 2; jj++)
                 if (s_pk[ww][jj] == k) {
                     any = true;
-                    const float *src = s_part + (size_t)(ww * 2 + jj) * NBT * 256;
+                    const float *src = s_part + (size_t)(ww * 2 + jj) * NA * 256;
 #pragma unroll
-                    for (int nb = 0; nb < NBT; nb++)
+                    for (int b = 0; b < NA; b++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[nb][r] += src[nb * 256 + r * 64 + l];
+                        for (int r = 0; r < 4; r++) acc[b][r] += src[b * 256 + r * 64 + l];
                 }
-        if (any || empty) {
-#pragma unroll
-            for (int nb = 0; nb < NBT; nb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int ci = blockIdx.z * 16 + 4 * q + r, j = 16 * nb + cl;
-                    if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[nb][r];
-                }
-        }
+        if (any || empty) store_slab(k, acc);
     }
 }
 
-template <int NBT>
+template <int NBT, int NCH>
 int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 {
-    // per wave: WGRAD_TB x (1 + NBT) transposition tiles + 2 x NBT boundary partials, 1 KB each
-    const size_t per_wave = ((size_t)WGRAD_TB * (1 + NBT) + 2 * NBT) * 256 * sizeof(float);
+    // per wave: WGRAD_TB x (NCH + NBT) transposition tiles + 2 x NCH*NBT boundary partials, 1 KB each
+    const size_t per_wave = ((size_t)WGRAD_TB * (NCH + NBT) + 2 * NCH * NBT) * 256 * sizeof(float);
     int nw = (int)(LDS_BUDGET / per_wave);
     if (nw > 16) nw = 16;
-    dim3 grid(nblk_rows, 1, ms3d_divup(p.Cin, 16));
+    dim3 grid(nblk_rows, 1, ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
     const size_t lds = (size_t)nw * per_wave;
     if (lds > 64 * 1024)
-        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_offsetlist_kernel<NBT>,
+        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    spconv_wgrad_offsetlist_kernel<NBT><<<grid, nw * 64, lds, stream>>>(p);
+    spconv_wgrad_offsetlist_kernel<NBT, NCH><<<grid, nw * 64, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1369,10 +1385,12 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     if (nb > 14) return MS3D_E_UNSUPPORTED;
     int rc;
     if (use_list) {
-        rc = nb == 1 ? launch_wgrad_offsetlist<1>(p, nblk, stream)
-           : nb == 2 ? launch_wgrad_offsetlist<2>(p, nblk, stream)
-           : nb == 3 ? launch_wgrad_offsetlist<3>(p, nblk, stream)
-                     : launch_wgrad_offsetlist<4>(p, nblk, stream);
+        // two input chunks per workgroup when Cin allows (entries and dout rows fetched once for both)
+        const bool two = ms3d_divup(Cin, 16) % 2 == 0 && nb <= 2;
+        rc = nb == 1 ? (two ? launch_wgrad_offsetlist<1, 2>(p, nblk, stream) : launch_wgrad_offsetlist<1, 1>(p, nblk, stream))
+           : nb == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
+           : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
+                     : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
         if (rc) return rc;
         wgrad_reduce_kernel<<<ms3d_divup(n, 16), 256, 0, stream>>>(partial_ws, nblk, n, dW);
         MS3D_LAUNCH_CHECK();
