@@ -126,15 +126,17 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                                                    int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
 {
     const int l = lane_id();
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
     for (int g0 = k_lo; g0 < k_hi; g0 += OG) {
         int idx[OG];
         load_indices(p, my_row, g0, k_hi, idx);
         bool any[OG];
 #pragma unroll
         for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
-        for (int ch = 0; ch < p.NCH; ch++) {
+        // rows (and the fused BN scale/shift) of one 16-channel chunk
+        auto fetch = [&](int ch, f32x4 (&a)[OG], f32x4 &sc, f32x4 &sh) {
             const int c0 = 16 * ch + 4 * q;
-            f32x4 a[OG];
 #pragma unroll
             for (int u = 0; u < OG; u++) {
                 const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
@@ -146,17 +148,34 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 }
             }
             if (p.pre_scale) {
-                f32x4 s, b;
                 if (ALIGNED) {
-                    s = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
-                    b = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
+                    sc = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
+                    sh = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        s[t] = (c0 + t < p.Cin) ? p.pre_scale[c0 + t] : 0.f;
-                        b[t] = (c0 + t < p.Cin) ? p.pre_shift[c0 + t] : 0.f;
+                        sc[t] = (c0 + t < p.Cin) ? p.pre_scale[c0 + t] : 0.f;
+                        sh[t] = (c0 + t < p.Cin) ? p.pre_shift[c0 + t] : 0.f;
                     }
                 }
+            }
+        };
+        // small levels (DIRECT): the next chunk's rows travel while this chunk is multiplied (one exposed round trip
+        // per chunk otherwise, 4..14 chunks per launch); `opaque0` keeps the compiler from folding the prefetch back
+        f32x4 a_next[OG], sc_next = {0.f, 0.f, 0.f, 0.f}, sh_next = sc_next;
+        if (DIRECT) fetch(0, a_next, sc_next, sh_next);
+        for (int ch = 0; ch < p.NCH; ch++) {
+            f32x4 a[OG], s = {0.f, 0.f, 0.f, 0.f}, b = s;
+            if (DIRECT) {
+#pragma unroll
+                for (int u = 0; u < OG; u++) a[u] = a_next[u];
+                s = sc_next;
+                b = sh_next;
+                if (ch + 1 < p.NCH) fetch(ch + 1 + opaque0, a_next, sc_next, sh_next);
+            } else {
+                fetch(ch, a, s, b);
+            }
+            if (p.pre_scale) {
 #pragma unroll
                 for (int u = 0; u < OG; u++)
 #pragma unroll
