@@ -368,8 +368,11 @@ __global__ __launch_bounds__(256) void glob_claim_kernel(Thr thr, const int16_t 
         const int lab = thr.mode == 0 ? (int)sem[node] : 0;
         for (int t = l; t < ln; t += 64) {
             const int j = ball_idx[st + t];
+            // claim first: of a node's ~300 incoming edges all but the first few find it visited or claimed by an
+            // earlier queue position, and then its label is never needed (two random reads per edge -> one)
+            if (claim[j] <= p) continue;  // stale reads are only ever too large -> a redundant atomic
             if (thr.mode == 0 && (int)sem[j] != lab) continue;
-            if (claim[j] > p) atomicMin(&claim[j], p);  // stale reads are only ever too large -> a redundant atomic
+            atomicMin(&claim[j], p);
         }
     }
 }
