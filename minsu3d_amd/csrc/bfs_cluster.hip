@@ -201,6 +201,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
 {
     __shared__ int s_pref[BFS_THREADS + 1];
     __shared__ int s_st[BFS_THREADS];
+    __shared__ int s_cnt[BFS_THREADS];
     __shared__ int s_wave[BFS_WAVES];
     __shared__ int s_bcast[2];
     const int tid = threadIdx.x;
@@ -246,6 +247,90 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                 int new_tail = tail;
                 for (int c0 = lvl_begin; c0 < lvl_end; c0 += BFS_THREADS) {
                     const int cn = min(BFS_THREADS, lvl_end - c0);
+                    // dense lists (capped shifted-coordinate graphs: up to 1000 neighbours) go one wave per frontier node;
+                    // short lists (raw coordinates: ~15 neighbours) keep the flat edge index, where no lane idles
+                    int dense_lists;
+                    {
+                        const int my_ln = tid < cn ? start_len[scratch_node[c0 + tid] * 2 + 1] : 0;
+                        int Etot;
+                        (void)block_excl_scan_512(my_ln, &Etot, s_wave);
+                        dense_lists = Etot >= cn * 48;
+                    }
+                    if (dense_lists) {
+                        // one wave per frontier node, lanes stride its neighbour list (the former flat edge index needed a
+                        // 9-step bisection per edge and a workgroup scan per 512 edges: 28 ms for 48 capped components)
+                        if (tid < cn) {
+                            const int node = scratch_node[c0 + tid];
+                            s_st[tid] = start_len[node * 2];
+                            s_pref[tid] = start_len[node * 2 + 1];   // length for now, winner offset later
+                        }
+                        __syncthreads();
+                        const int wv = tid >> 6, ln_ = tid & 63;
+                        // ---- phase A: every out-edge to an unvisited, label-compatible node posts its parent position
+                        int any = 0;
+                        for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                            const int st = s_st[pos], ln = s_pref[pos];
+                            for (int t = ln_; t < ln; t += 64) {
+                                const int j = ball_idx[st + t];
+                                if (visited[j]) continue;
+                                if (thr.mode == 0 && (int)sem[j] != lab) continue;
+                                if (ld_agent(&claim[j]) > pos) atomicMin(&claim[j], pos);
+                                any = 1;
+                            }
+                        }
+                        any = __syncthreads_or(any);
+                        if (any) {
+                            // ---- phase B1: winners per node
+                            int my_cnt = 0;
+                            for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                                const int st = s_st[pos], ln = s_pref[pos];
+                                int c = 0;
+                                for (int t0 = 0; t0 < ln; t0 += 64) {
+                                    const int t = t0 + ln_;
+                                    bool win = false;
+                                    if (t < ln) {
+                                        const int j = ball_idx[st + t];
+                                        win = visited[j] == 0 && (thr.mode != 0 || (int)sem[j] == lab) && ld_agent(&claim[j]) == pos;
+                                    }
+                                    c += __popcll(__ballot(win));
+                                }
+                                if (ln_ == 0) s_cnt[pos] = c;
+                            }
+                            __syncthreads();
+                            my_cnt = tid < cn ? s_cnt[tid] : 0;
+                            int tot;
+                            const int off = block_excl_scan_512(my_cnt, &tot, s_wave);
+                            if (tid < cn) s_cnt[tid] = off;
+                            __syncthreads();
+                            // ---- phase B2: winners compacted in (parent position, slot) order
+                            for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                                const int st = s_st[pos], ln = s_pref[pos];
+                                int out = new_tail + s_cnt[pos];
+                                for (int t0 = 0; t0 < ln; t0 += 64) {
+                                    const int t = t0 + ln_;
+                                    bool win = false;
+                                    int j = -1;
+                                    if (t < ln) {
+                                        j = ball_idx[st + t];
+                                        win = visited[j] == 0 && (thr.mode != 0 || (int)sem[j] == lab) && ld_agent(&claim[j]) == pos;
+                                    }
+                                    const unsigned long long m = __ballot(win);
+                                    if (win) {
+                                        const int o = out + ballot_rank(m);
+                                        scratch_node[o] = j;
+                                        scratch_seed[o] = seed;
+                                    }
+                                    out += __popcll(m);
+                                }
+                            }
+                            __syncthreads();
+                            // mark the winners visited only now: phase B2 of another wave must still see them unvisited
+                            for (int o = new_tail + tid; o < new_tail + tot; o += BFS_THREADS) visited[scratch_node[o]] = 1;
+                            new_tail += tot;
+                        }
+                        __syncthreads();
+                        continue;
+                    }
                     int ln = 0, st = 0;
                     if (tid < cn) {
                         const int node = scratch_node[c0 + tid];
