@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int BFS_THREADS = 512;
+constexpr int BFS_THREADS = 1024;  // largest replay workgroup (LDS arrays are sized for it); the launch picks 512 or 1024
 constexpr int BFS_WAVES = BFS_THREADS / 64;
 constexpr int INT_BIG = 0x7fffffff;
 
@@ -164,6 +164,7 @@ __global__ void bfs_select_kernel(int N, Thr thr, const int *__restrict__ root, 
     if (root[i] == i && qualifies(thr, comp_size[i], i)) worklist[atomicAdd(&counters[0], 1)] = i;
 }
 
+template <int NTHREADS>
 __device__ __forceinline__ int block_excl_scan_512(int v, int *total, int *s_wave)
 {
     const int incl = wave_incl_scan(v);
@@ -171,7 +172,7 @@ __device__ __forceinline__ int block_excl_scan_512(int v, int *total, int *s_wav
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < BFS_WAVES; w++) {
+    for (int w = 0; w < NTHREADS / 64; w++) {
         const int t = s_wave[w];
         if (w < wave_id()) base += t;
         tot += t;
@@ -180,6 +181,7 @@ __device__ __forceinline__ int block_excl_scan_512(int v, int *total, int *s_wav
     *total = tot;
     return base + incl - v;
 }
+template <int NTHREADS>
 __device__ __forceinline__ int block_min_512(int v, int *s_wave)
 {
     v = wave_min(v);
@@ -187,24 +189,26 @@ __device__ __forceinline__ int block_min_512(int v, int *s_wave)
     __syncthreads();
     int m = INT_BIG;
 #pragma unroll
-    for (int w = 0; w < BFS_WAVES; w++) m = min(m, s_wave[w]);
+    for (int w = 0; w < NTHREADS / 64; w++) m = min(m, s_wave[w]);
     __syncthreads();
     return m;
 }
 
 // counters: [0] nwork  [1] next work item  [2] scratch cursor
-__global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void bfs_expand_kernel(
     int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
     const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ comp_size,
     const int *__restrict__ worklist, int *counters, int *visited, int *claim, int *scratch_node, int *scratch_seed,
     int *cl_size, int *cl_start)
 {
-    __shared__ int s_pref[BFS_THREADS + 1];
-    __shared__ int s_st[BFS_THREADS];
-    __shared__ int s_cnt[BFS_THREADS];
-    __shared__ int s_wave[BFS_WAVES];
+    __shared__ int s_pref[NT + 1];
+    __shared__ int s_st[NT];
+    __shared__ int s_cnt[NT];
+    __shared__ int s_wave[NT / 64];
     __shared__ int s_bcast[2];
     const int tid = threadIdx.x;
+    constexpr int NW = NT / 64;  // NT = 512 threads for sparse graphs, 1024 for dense / capped ones
     const int nwork = ld_agent(&counters[0]);
 
     for (;;) {
@@ -226,10 +230,10 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
             if (done > 0) {
                 // next seed: smallest unvisited member of this component above the previous seed
                 int found = INT_BIG;
-                for (int c = seed + 1; c < N && found == INT_BIG; c += BFS_THREADS) {
+                for (int c = seed + 1; c < N && found == INT_BIG; c += NT) {
                     const int i = c + tid;
                     const int cand = (i < N && root[i] == r && visited[i] == 0) ? i : INT_BIG;
-                    found = block_min_512(cand, s_wave);
+                    found = block_min_512<NT>(cand, s_wave);
                 }
                 seed = found;
                 if (seed == INT_BIG) break;  // cannot happen: done < sz guarantees a member is left
@@ -245,17 +249,12 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
             __syncthreads();
             while (lvl_begin < lvl_end) {
                 int new_tail = tail;
-                for (int c0 = lvl_begin; c0 < lvl_end; c0 += BFS_THREADS) {
-                    const int cn = min(BFS_THREADS, lvl_end - c0);
+                for (int c0 = lvl_begin; c0 < lvl_end; c0 += NT) {
+                    const int cn = min(NT, lvl_end - c0);
                     // dense lists (capped shifted-coordinate graphs: up to 1000 neighbours) go one wave per frontier node;
                     // short lists (raw coordinates: ~15 neighbours) keep the flat edge index, where no lane idles
-                    int dense_lists;
-                    {
-                        const int my_ln = tid < cn ? start_len[scratch_node[c0 + tid] * 2 + 1] : 0;
-                        int Etot;
-                        (void)block_excl_scan_512(my_ln, &Etot, s_wave);
-                        dense_lists = Etot >= cn * 48;
-                    }
+                    // NT == 1024 is launched for dense graphs (n_edges >= 24 N) only
+                    constexpr bool dense_lists = NT == 1024;
                     if (dense_lists) {
                         // one wave per frontier node, lanes stride its neighbour list (the former flat edge index needed a
                         // 9-step bisection per edge and a workgroup scan per 512 edges: 28 ms for 48 capped components)
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                         const int wv = tid >> 6, ln_ = tid & 63;
                         // ---- phase A: every out-edge to an unvisited, label-compatible node posts its parent position
                         int any = 0;
-                        for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                        for (int pos = wv; pos < cn; pos += NW) {
                             const int st = s_st[pos], ln = s_pref[pos];
                             for (int t = ln_; t < ln; t += 64) {
                                 const int j = ball_idx[st + t];
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                         if (any) {
                             // ---- phase B1: winners per node
                             int my_cnt = 0;
-                            for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                            for (int pos = wv; pos < cn; pos += NW) {
                                 const int st = s_st[pos], ln = s_pref[pos];
                                 int c = 0;
                                 for (int t0 = 0; t0 < ln; t0 += 64) {
@@ -299,11 +298,11 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                             __syncthreads();
                             my_cnt = tid < cn ? s_cnt[tid] : 0;
                             int tot;
-                            const int off = block_excl_scan_512(my_cnt, &tot, s_wave);
+                            const int off = block_excl_scan_512<NT>(my_cnt, &tot, s_wave);
                             if (tid < cn) s_cnt[tid] = off;
                             __syncthreads();
                             // ---- phase B2: winners compacted in (parent position, slot) order
-                            for (int pos = wv; pos < cn; pos += BFS_WAVES) {
+                            for (int pos = wv; pos < cn; pos += NW) {
                                 const int st = s_st[pos], ln = s_pref[pos];
                                 int out = new_tail + s_cnt[pos];
                                 for (int t0 = 0; t0 < ln; t0 += 64) {
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                             }
                             __syncthreads();
                             // mark the winners visited only now: phase B2 of another wave must still see them unvisited
-                            for (int o = new_tail + tid; o < new_tail + tot; o += BFS_THREADS) visited[scratch_node[o]] = 1;
+                            for (int o = new_tail + tid; o < new_tail + tot; o += NT) visited[scratch_node[o]] = 1;
                             new_tail += tot;
                         }
                         __syncthreads();
@@ -338,14 +337,14 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                         ln = start_len[node * 2 + 1];
                     }
                     int E;
-                    const int ex = block_excl_scan_512(ln, &E, s_wave);
+                    const int ex = block_excl_scan_512<NT>(ln, &E, s_wave);
                     s_pref[tid] = ex;
                     s_st[tid] = st;
-                    if (tid == 0) s_pref[BFS_THREADS] = E;
+                    if (tid == 0) s_pref[NT] = E;
                     __syncthreads();
                     // ---- phase A: every out-edge to an unvisited, label-compatible node posts its parent position
                     int any = 0;
-                    for (int e = tid; e < E; e += BFS_THREADS) {
+                    for (int e = tid; e < E; e += NT) {
                         int lo = 0, hi = cn;  // largest p with pref[p] <= e
                         while (hi - lo > 1) {
                             const int mid = (lo + hi) >> 1;
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                     any = __syncthreads_or(any);
                     if (any) {
                         // ---- phase B: winners, compacted in (parent position, slot) order
-                        for (int e0 = 0; e0 < E; e0 += BFS_THREADS) {
+                        for (int e0 = 0; e0 < E; e0 += NT) {
                             const int e = e0 + tid;
                             int win = 0, j = -1;
                             if (e < E) {
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(BFS_THREADS) void bfs_expand_kernel(
                                 if (ok && ld_agent(&claim[j]) == lo) win = 1;
                             }
                             int tot;
-                            const int rank = block_excl_scan_512(win, &tot, s_wave);
+                            const int rank = block_excl_scan_512<NT>(win, &tot, s_wave);
                             if (win) {
                                 scratch_node[new_tail + rank] = j;
                                 scratch_seed[new_tail + rank] = seed;
@@ -674,7 +673,12 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         }
     }
     if (replay) {
-        bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+        if (n_edges >= (long)N * 24)
+            bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        else
+            bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
                                                               w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
                                                               w.scratch_seed, w.cl_size, w.cl_start);
         MS3D_LAUNCH_CHECK();
@@ -714,7 +718,12 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         MS3D_LAUNCH_CHECK();
         bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
         MS3D_LAUNCH_CHECK();
-        bfs_expand_kernel<<<256 * 2, BFS_THREADS, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+        if (n_edges >= (long)N * 24)
+            bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        else
+            bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
                                                               w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
                                                               w.scratch_seed, w.cl_size, w.cl_start);
         MS3D_LAUNCH_CHECK();
