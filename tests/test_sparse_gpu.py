@@ -273,3 +273,17 @@ def test_pair_lists_bit_exact(be, oracle, K):
             seg = ent[starts[t, k]: starts[t, k] + 16 * nb[t, k]]
             assert np.array_equal(seg[:len(r), 0], nbr[k, t * 64 + r]) and np.array_equal(seg[:len(r), 1], (k << 8) | r)
             assert np.all(seg[len(r):, 0] == 0) and np.all(seg[len(r):, 1] == ((k << 8) | 64))
+
+
+def test_list_kernels_on_small_and_ragged_levels():
+    """the pair-list / offset-list kernels are selected by row count; forced on for every size (the knob is read once
+    per process, hence the child process) they must pass the same parity checks on the small, ragged test shapes"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MS3D_PAIRLIST_MIN_ROWS="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_sparse_gpu.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "conv_kernels_vs_oracle or mini_unet"], env=env, cwd=os.path.dirname(here),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
