@@ -247,6 +247,20 @@ def _f32(t):
     return None if t is None else t.contiguous()
 
 
+def _p(t):
+    """raw pointer (int) of a contiguous tensor or None -- for entry points whose argtypes are declared (no ctypes
+    object per argument: the per-layer calls are made ~250 times per step)"""
+    return None if t is None else t.data_ptr()
+
+
+_VP, _I = C.c_void_p, C.c_int
+_FAST_ARGTYPES = {
+    "ms3d_spconv_layer_forward": [_VP] * 3 + [_I] * 5 + [_VP] * 2 + [_I] + [_VP] * 5 + [_VP] * 2 + [_VP] * 2 + [_VP],
+    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 2 + [_VP],
+    "ms3d_bn_finalize": [_VP, _I, C.c_long, _I, C.c_float, C.c_float] + [_VP] * 4 + [_VP] * 4 + [_VP],
+}
+
+
 class KernelTimer:
     """Times selected kernel launches with HIP events recorded INSIDE the library call, immediately before and
     after the kernel on the stream it is launched on, and keeps the algorithmic byte count of each launch
@@ -488,6 +502,17 @@ class _HipEngine:
         return pick[:int(n_pick.item())]
 
     # ---- one library call per layer and direction (used by MinkowskiEngine/functional.py)
+    def _fast(self, name):
+        """library entry point with declared argtypes (plain ints / None for pointers)"""
+        cache = self.__dict__.setdefault("_fast_cache", {})
+        fn = cache.get(name)
+        if fn is None:
+            fn = getattr(self.lib, name)
+            fn.argtypes = _FAST_ARGTYPES[name]
+            fn.restype = C.c_int
+            cache[name] = fn
+        return fn
+
     def _geom(self, what, *key):
         """launch-geometry queries of the library, memoised (three ctypes calls per layer otherwise)"""
         cache = self.__dict__.setdefault("_geom_cache", {})
@@ -517,10 +542,10 @@ class _HipEngine:
         timer = self.kernel_timer
         tok = timer.begin("spconv_fwd", K, cin, cout, nbr_fwd) if timer is not None else None
         ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
-        _lib.check(self.lib.ms3d_spconv_layer_forward(
-            _lib.ptr(x), _lib.ptr(self._dev(W3)), _lib.ptr(nbr_fwd), int(vout), int(K), int(cin), int(cout),
-            int(bool(mirror_bwd)), _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
-            _lib.ptr(_f32(bias)), _lib.ptr(wf_buf), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(pl[0]), _lib.ptr(pl[1]),
+        _lib.check(self._fast("ms3d_spconv_layer_forward")(
+            _p(x), _p(self._dev(W3)), _p(nbr_fwd), int(vout), int(K), int(cin), int(cout),
+            int(bool(mirror_bwd)), _p(_f32(ps)), _p(_f32(pb)), int(bool(pre_relu)), _p(_f32(residual)),
+            _p(_f32(bias)), _p(wf_buf), _p(y), _p(stats), _p(pl[0]), _p(pl[1]),
             ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")
         return y, stats, wf_buf
 
@@ -539,13 +564,13 @@ class _HipEngine:
         timer = self.kernel_timer
         tok = timer.begin("spconv_fwd", K, cout, cin, nbr_bwd) if (timer is not None and want_dx) else None
         ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
-        _lib.check(self.lib.ms3d_spconv_layer_backward(
-            _lib.ptr(x), _lib.ptr(dy), _lib.ptr(wf_buf), _lib.ptr(nbr_fwd), _lib.ptr(nbr_bwd), int(vin), int(vout), int(K),
-            int(cin), int(cout), _lib.ptr(bn["scale"] if has_bn else None), _lib.ptr(bn["shift"] if has_bn else None),
-            _lib.ptr(bn["mean"] if has_bn else None), _lib.ptr(bn["invstd"] if has_bn else None),
-            int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _lib.ptr(dx),
-            _lib.ptr(dgb), _lib.ptr(dW), _lib.ptr(ws), _lib.ptr(plf[0]), _lib.ptr(plf[1]), _lib.ptr(plb[0]),
-            _lib.ptr(plb[1]), ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_backward")
+        _lib.check(self._fast("ms3d_spconv_layer_backward")(
+            _p(x), _p(dy), _p(wf_buf), _p(nbr_fwd), _p(nbr_bwd), int(vin), int(vout), int(K),
+            int(cin), int(cout), _p(bn["scale"] if has_bn else None), _p(bn["shift"] if has_bn else None),
+            _p(bn["mean"] if has_bn else None), _p(bn["invstd"] if has_bn else None),
+            int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
+            _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
+            _p(plb[1]), ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_backward")
         return (dx if need_dx else None), dgb, dW
 
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):
@@ -583,12 +608,13 @@ class _HipEngine:
         """statistics from the (sum, sum of squares) partials a conv epilogue left behind -> (mean, invstd, scale, shift)"""
         C_ = partial.size(2)
         outs = torch.empty((4, C_), dtype=torch.float32, device=partial.device)
-        _lib.check(self.lib.ms3d_bn_finalize(_lib.ptr(partial), int(partial.size(0)), C.c_long(V), int(C_),
-                                             C.c_float(eps), C.c_float(momentum), _lib.ptr(_f32(gamma)),
-                                             _lib.ptr(_f32(beta)), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                             _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), _lib.ptr(outs[3]),
-                                             _lib.stream_handle()), "ms3d_bn_finalize")
-        return outs[0], outs[1], outs[2], outs[3]
+        base, row = outs.data_ptr(), 4 * C_
+        _lib.check(self._fast("ms3d_bn_finalize")(_p(partial), int(partial.size(0)), int(V), int(C_),
+                                                  float(eps), float(momentum), _p(_f32(gamma)),
+                                                  _p(_f32(beta)), _p(running_mean), _p(running_var),
+                                                  base, base + row, base + 2 * row, base + 3 * row,
+                                                  _lib.stream_handle()), "ms3d_bn_finalize")
+        return outs.unbind(0)
 
     def bn_apply(self, x, scale, shift, relu):
         x = self._dev(x)
