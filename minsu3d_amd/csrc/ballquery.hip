@@ -130,6 +130,40 @@ __device__ __forceinline__ int candidate_pos(int t, const int *s_prefix, const i
     return s_start[lo] + (t - s_prefix[lo]);
 }
 
+constexpr int BQ_MED = 512;  // hit lists up to this length are sorted in registers
+
+// ascending bitonic sort of 512 keys, key e = 8 * lane + r
+__device__ __forceinline__ void bitonic_sort_512(int (&v)[8])
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 512; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 8) {
+                const int lj = j >> 3;
+                const bool lower = (l & lj) == 0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const bool asc = ((l * 8 + r) & k) == 0;
+                    const int o = __shfl_xor(v[r], lj, 64);
+                    v[r] = (lower == asc) ? min(v[r], o) : max(v[r], o);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if ((r & j) != 0) continue;
+                    const bool asc = ((l * 8 + r) & k) == 0;
+                    const int a = v[r], b = v[r | j];
+                    const int lo = min(a, b), hi = max(a, b);
+                    v[r] = asc ? lo : hi;
+                    v[r | j] = asc ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, float inv_cell, long thre,
                                                        const float *__restrict__ xyz,
@@ -144,11 +178,11 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
                                                        int bitmap_words, int *flags)
 {
     extern __shared__ int lds[];
-    const int per_wave = 28 + 27 + 64 + (FILL ? bitmap_words : 0);
+    const int per_wave = 28 + 27 + (FILL ? BQ_MED + bitmap_words : 64);
     int *s_prefix = lds + wave_id() * per_wave;
     int *s_start = s_prefix + 28;
     int *s_hits = s_start + 27;
-    unsigned *s_bits = (unsigned *)(s_hits + 64);
+    unsigned *s_bits = (unsigned *)(s_hits + (FILL ? BQ_MED : 64));
     const int l = lane_id();
     const int waves = blockDim.x >> 6;
     const float r2 = radius * radius;  // bfs_cluster.cu:23
@@ -168,13 +202,14 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
         const int total = gather_cells(b, cell_coord(ox, inv_cell), cell_coord(oy, inv_cell), cell_coord(oz, inv_cell),
                                        keys, cell_start, cell_count, mask, s_prefix, s_start);
         int my_len = 0, my_start = 0, sbeg = 0;
-        bool small = true;
+        bool small = true, medium = false;  // <= 64 hits: one bitonic pass in registers; <= 512: LDS list + 512-key sort
         if (FILL) {
             my_len = len[i];
             my_start = start[i];
             small = my_len <= 64;
+            medium = !small && my_len <= BQ_MED;
             sbeg = batch_offsets[b];
-            if (!small && (batch_offsets[b + 1] - sbeg) > bitmap_words * 32) {
+            if (!small && !medium && (batch_offsets[b + 1] - sbeg) > bitmap_words * 32) {
                 if (l == 0) atomicOr(flags, 1);  // scene larger than the LDS bitmap
                 continue;
             }
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
                 const int k = __float_as_int(p[u].w);
                 const unsigned long long m = __ballot(hit);
                 if (FILL && hit) {
-                    if (small)
+                    if (small || medium)
                         s_hits[nhits + ballot_rank(m)] = k;
                     else {
                         const int w = (k - sbeg) >> 5;
@@ -241,6 +276,19 @@ __global__ __launch_bounds__(256) void bq_query_kernel(int n, float radius, floa
                     v = (lower == asc) ? min(v, o) : max(v, o);
                 }
             if (l < my_len && (long)my_start + l < thre) idx[my_start + l] = v;
+        } else if (medium) {
+            // 65..512 hits (the bulk of a shifted-coordinate query): 8 keys per lane, bitonic network over 512 keys.
+            // The scene-wide bitmap below costs a scan of the whole scene's index range per query when the hits are
+            // scattered over it (a scan permutes its points): ~2500 instructions against ~1000 here.
+            int v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = (l * 8 + r < my_len) ? s_hits[l * 8 + r] : 0x7fffffff;
+            bitonic_sort_512(v);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int e = l * 8 + r;
+                if (e < my_len && (long)my_start + e < thre) idx[my_start + e] = v[r];
+            }
         } else {
             // ordered emission of the first `my_len` set bits; lanes take interleaved words so runs of
             // consecutive indices spread over the wave
@@ -371,9 +419,9 @@ int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz
         int bits = max_scene_points > 0 ? max_scene_points : DEFAULT_BITMAP_BITS;
         if (bits > n) bits = n;
         const int words = (ms3d_divup(bits, 32) + 63) / 64 * 64;
-        const size_t per_wave = sizeof(int) * (size_t)(28 + 27 + 64 + words);
+        const size_t per_wave = sizeof(int) * (size_t)(28 + 27 + BQ_MED + words);
         if (per_wave > 150 * 1024) return MS3D_E_UNSUPPORTED;
-        int waves = (int)((60 * 1024) / per_wave);
+        int waves = (int)((64 * 1024) / per_wave);
         waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
         const size_t lds = per_wave * waves;
         if (lds > 64 * 1024)
