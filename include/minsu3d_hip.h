@@ -70,6 +70,7 @@ int ms3d_sg_bfs_cluster_batched(const uint8_t *group_of_point, const float *thr_
 size_t ms3d_hais_workspace_bytes(int N, int nclass);
 int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *coord_shift, const uint8_t *batch_idxs,
                                   const int *ball_query_idxs, long n_edges, const int *start_len, int N,
+                                  int capped_hint /* as for ms3d_pg_bfs_cluster */,
                                   int using_set_aggr, const float *point_num_avg /*[host]*/,
                                   const float *radius_avg /*[host]*/, int nclass, int *cluster_idxs,
                                   int *cluster_offsets, int *counts /*[host,2]*/, void *workspace,

@@ -139,6 +139,7 @@ class HipBackend:
 
     def hierarchical_aggregation(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
                                  point_num_avg, radius_avg, ignored_label=-1):
+        hint = int(getattr(start_len, "_ms3d_capped", -1))   # set by ballquery_batch_p on the tensor it returned
         sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)
         start_len = self._dev(start_len); batch_idxs = self._dev(batch_idxs)
         assert sem.dtype == torch.int16 and batch_idxs.dtype == torch.uint8
@@ -152,7 +153,7 @@ class HipBackend:
         counts = (C.c_int * 2)(0, 0)
         _lib.check(self.lib.ms3d_hierarchical_aggregation(
             _lib.ptr(sem), _lib.ptr(cs), _lib.ptr(batch_idxs), _lib.ptr(ball_idx), C.c_long(ball_idx.numel()),
-            _lib.ptr(start_len), N, int(bool(using_set_aggr)), pna, ra, ncls, _lib.ptr(out_idx), _lib.ptr(out_off),
+            _lib.ptr(start_len), N, hint, int(bool(using_set_aggr)), pna, ra, ncls, _lib.ptr(out_idx), _lib.ptr(out_off),
             counts, _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_hierarchical_aggregation")
         return out_idx[:counts[1]], out_off[:counts[0] + 1]
 

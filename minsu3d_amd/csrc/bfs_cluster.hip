@@ -590,8 +590,8 @@ size_t carve(BfsWorkspace &w, int N, void *base)
 }  // namespace
 
 // also used by hais.hip (mode 0, threshold 0 = every connected component)
-int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, const int *ball_idx, long n_edges,
-                          const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
+int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, int capped_hint, const int16_t *sem, const int *ball_idx,
+                          long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
                           void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 namespace {
@@ -735,12 +735,12 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
 
 }  // namespace
 
-int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, const int *ball_idx, long n_edges,
-                          const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
+int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, int capped_hint, const int16_t *sem, const int *ball_idx,
+                          long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
                           void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     Thr thr{mode, thr_i, thr_f, nullptr, nullptr};
-    return bfs_run(thr, -1, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
+    return bfs_run(thr, capped_hint, sem, ball_idx, n_edges, start_len, N, cluster_idxs, cluster_offsets, counts, workspace,
                    workspace_bytes, stream);
 }
 

@@ -15,8 +15,8 @@
 #include "scan.h"
 #include "../../include/minsu3d_hip.h"
 
-int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, const int16_t *sem, const int *ball_idx, long n_edges,
-                          const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
+int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, int capped_hint, const int16_t *sem, const int *ball_idx,
+                          long n_edges, const int *start_len, int N, int *cluster_idxs, int *cluster_offsets, int *counts,
                           void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 namespace {
@@ -201,7 +201,7 @@ size_t ms3d_hais_workspace_bytes(int N, int nclass)
 }
 
 int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *coord_shift, const uint8_t *batch_idxs,
-                                  const int *ball_query_idxs, long n_edges, const int *start_len, int N,
+                                  const int *ball_query_idxs, long n_edges, const int *start_len, int N, int capped_hint,
                                   int using_set_aggr, const float *point_num_avg /*[host]*/,
                                   const float *radius_avg /*[host]*/, int nclass, int *cluster_idxs /*[2N,2]*/,
                                   int *cluster_offsets /*[N+1]*/, int *counts /*[host,2]*/, void *workspace,
@@ -218,7 +218,7 @@ int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *co
     MS3D_CHECK(hipMemcpyAsync(w.avg, point_num_avg, sizeof(float) * nclass, hipMemcpyHostToDevice, stream));
     MS3D_CHECK(hipMemcpyAsync(w.avg + nclass, radius_avg, sizeof(float) * nclass, hipMemcpyHostToDevice, stream));
     int cc_counts[2];
-    int rc = ms3d_bfs_run_internal(0, 0, 0.f, semantic_label, ball_query_idxs, n_edges, start_len, N, w.cc_idx, w.cc_off,
+    int rc = ms3d_bfs_run_internal(0, 0, 0.f, capped_hint, semantic_label, ball_query_idxs, n_edges, start_len, N, w.cc_idx, w.cc_off,
                                    cc_counts, w.bfs_ws, w.bfs_bytes, stream);
     if (rc) return rc;
     const int ncc = cc_counts[0];
