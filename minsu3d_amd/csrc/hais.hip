@@ -33,16 +33,31 @@ __global__ void ha_describe_kernel(int ncc, const int *__restrict__ cc_idx, cons
                                    const uint8_t *__restrict__ batch_idxs, const float *__restrict__ point_num_avg,
                                    CC *cc)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one WAVE per component: the lanes fetch 64 members at a time (index -> coordinates, two dependent loads that one
+    // thread per component paid once per member: 2.4 ms on a 5000-point component), then every lane adds them up in
+    // member order -- serial, in BFS order: the same float sum as the reference
+    const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
     if (c >= ncc) return;
+    const int l = lane_id();
     const int s = cc_off[c], e = cc_off[c + 1];
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int q = s; q < e; q++) {  // serial, in BFS order: same float sum as the reference
-        const int i = cc_idx[q * 2 + 1];
-        ax += coord_shift[i * 3 + 0];
-        ay += coord_shift[i * 3 + 1];
-        az += coord_shift[i * 3 + 2];
+    for (int q0 = s; q0 < e; q0 += 64) {
+        const int q = q0 + l;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (q < e) {
+            const int i = cc_idx[q * 2 + 1];
+            x = coord_shift[i * 3 + 0];
+            y = coord_shift[i * 3 + 1];
+            z = coord_shift[i * 3 + 2];
+        }
+        const int n = min(64, e - q0);
+        for (int k = 0; k < n; k++) {
+            ax += __shfl(x, k, 64);
+            ay += __shfl(y, k, 64);
+            az += __shfl(z, k, 64);
+        }
     }
+    if (l != 0) return;
     const int seed = cc_idx[s * 2 + 1];
     const int size = e - s;
     CC o;
@@ -223,7 +238,7 @@ int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *co
     if (rc) return rc;
     const int ncc = cc_counts[0];
     const int nb = ms3d_divup(ncc, 128);
-    ha_describe_kernel<<<nb, 128, 0, stream>>>(ncc, w.cc_idx, w.cc_off, semantic_label, coord_shift, batch_idxs, w.avg, w.cc);
+    ha_describe_kernel<<<ms3d_divup((long)ncc * 64, 256), 256, 0, stream>>>(ncc, w.cc_idx, w.cc_off, semantic_label, coord_shift, batch_idxs, w.avg, w.cc);
     MS3D_LAUNCH_CHECK();
     if (using_set_aggr) {
         ha_nearest_kernel<<<nb, 128, 0, stream>>>(ncc, w.cc, w.avg + nclass, w.absorb_to);
