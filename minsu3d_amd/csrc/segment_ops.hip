@@ -47,8 +47,19 @@ __global__ __launch_bounds__(256) void seg_serial_sum_kernel(int P, int C, const
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave landed
-                if (l < cw)
-                    for (int r = 0; r < rows; r++) acc += t[r * cw + l];
+                if (l < cw) {
+                    // 8 LDS reads issued together, then added in row order (one read per dependent add paid the LDS
+                    // latency for every member of the proposal)
+                    int r = 0;
+                    for (; r + 8 <= rows; r += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = t[(r + u) * cw + l];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) acc += v[u];
+                    }
+                    for (; r < rows; r++) acc += t[r * cw + l];
+                }
                 __builtin_amdgcn_wave_barrier();
             }
             if (l < cw) {
