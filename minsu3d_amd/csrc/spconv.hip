@@ -189,21 +189,39 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 const int keep = ~(idx[u] >> 31);  // absent neighbour (idx < 0) contributes nothing
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
-                // DIRECT (small levels): no skip -- a uniform branch in front of the B-fragment loads makes the compiler
-                // issue them inside the branch and wait on the spot: one L2 round trip per offset, 63 in a row on a
-                // 112-channel level (34 us for 112 rows).  Straight-line code lets the loads of all offsets go out together.
-                if (!DIRECT && !any[u]) continue;
-                if (DIRECT) {
-                    // small levels: B fragments straight from the global image (L2 resident), no LDS staging
-                    // offsets past K (last group) multiply zeros: clamp the read to the last real offset's image
-                    const float *w = p.wf + ((size_t)((min(g0 + u, p.K - 1) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+            }
+            if (DIRECT) {
+                // small levels: B fragments straight from the global image (L2 resident), no LDS staging, and NO skip of
+                // empty offsets: a uniform branch in front of the fragment loads makes the compiler issue them inside
+                // the branch and wait on the spot (one L2 round trip per offset, 63 in a row on a 112-channel level).
+                // The fragments of UB offsets are requested together (explicit register arrays: left alone the
+                // scheduler keeps ~9 loads in flight, and a tiny level is exactly this chain of round trips).
+                constexpr int UB = NBT <= 2 ? OG : (NBT <= 4 ? 3 : 1);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
+                for (int u0 = 0; u0 < OG; u0 += UB) {
+                    float wreg[UB][4][NBT];
 #pragma unroll
-                        for (int nb = 0; nb < NBT; nb++)
-                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(size_t)(t * p.NBtot + nb) * 64], acc[nb], 0, 0, 0);
+                    for (int uu = 0; uu < UB; uu++) {
+                        // offsets past K (last group) multiply zeros: clamp the read to the last real offset's image
+                        const float *w = p.wf + ((size_t)((min(g0 + u0 + uu, p.K - 1) * p.NCH + ch) * 4) * p.NBtot + nb0) * 64 + l;
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int nb = 0; nb < NBT; nb++) wreg[uu][t][nb] = w[(size_t)(t * p.NBtot + nb) * 64];
                     }
-                } else {
+                    __builtin_amdgcn_sched_barrier(0);  // keep the loads above the multiplies (the scheduler re-interleaves them)
+#pragma unroll
+                    for (int uu = 0; uu < UB; uu++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int nb = 0; nb < NBT; nb++)
+                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u0 + uu][t], wreg[uu][t][nb], acc[nb], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < OG; u++) {
+                    if (!any[u]) continue;
                     // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
                     const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
 #pragma unroll
