@@ -147,10 +147,14 @@ int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_do
 /* Pair list = tile-compacted form of an offset-major table, built once per table and shared by every convolution of
  * the level (forward, backward-data, backward-weight).  Output rows are cut into tiles of 64; per tile and offset the
  * valid (input row, output row) pairs are stored contiguously, padded to a multiple of 16 ("batch" = one MFMA group).
- *   tile_start[tiles + 1]   first batch of each tile (exclusive scan; last = number of batches)
+ *   tile_start[header_ints] tiles + 1 batch offsets (exclusive scan; last = number of batches), then the schedule of
+ *                           the kernels that walk the list: part_start[257] cuts the tiles into 256 parts of near-equal
+ *                           batch count (tile t is in part floor(256 * tile_start[t] / batches)), order[tiles] lists
+ *                           the tiles of each part by descending batch count (stable, per run of 64 tiles)
  *   entries[2 * 16 * batches]  int2 per pair: (input row, (k << 8) | output row inside the tile); pad = (0, k<<8 | 64)
  * capacity() is the worst case in entries (allocate 8 bytes each); only the used prefix is ever touched. */
 int ms3d_kmap_pairlist_tiles(int Vout);
+int ms3d_kmap_pairlist_header_ints(int Vout);
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout);
 int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
                              size_t workspace_bytes /* >= ms3d_coord_workspace_bytes(1) */, ms3d_stream_t stream);

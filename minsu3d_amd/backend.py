@@ -408,8 +408,8 @@ class _HipEngine:
             if self.lib.ms3d_kmap_pairlist_wanted(int(K), int(vout)):
                 self.lib.ms3d_kmap_pairlist_capacity.restype = C.c_size_t
                 cap = self.lib.ms3d_kmap_pairlist_capacity(int(K), int(vout))
-                tiles = self.lib.ms3d_kmap_pairlist_tiles(int(vout))
-                tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=nbr.device)
+                tile_start = torch.empty(self.lib.ms3d_kmap_pairlist_header_ints(int(vout)), dtype=torch.int32,
+                                         device=nbr.device)
                 entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
                 ws = self._cws(1, nbr.device)
                 _lib.check(self.lib.ms3d_kmap_pairlist_build(_lib.ptr(nbr), int(K), int(vout), _lib.ptr(tile_start),

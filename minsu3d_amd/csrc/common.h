@@ -5,6 +5,7 @@
 
 #define MS3D_WAVE 64
 #define MS3D_PL_ROWS 64  // output rows per tile of a pair list (ms3d_kmap_pairlist_build)
+#define MS3D_PL_PARTS 256  // a pair list is cut into this many parts of near-equal batch count (one per block of a launch)
 
 // Every launcher returns 0 on success or a non-zero hipError_t; nothing ever calls exit().
 #define MS3D_CHECK(expr)                                   \

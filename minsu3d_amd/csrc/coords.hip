@@ -266,6 +266,46 @@ __global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restric
     }
 }
 
+// Schedule of a pair list for the kernels that walk it.  A wave works through a tile as a chain of dependent round
+// trips per batch group, tiles differ ~4x in batches (14..63 on 2 cm scans) and neighbouring tiles are correlated, so
+// a launch lasts as long as its most loaded wave.  The tiles are therefore cut into MS3D_PL_PARTS parts of near-equal
+// batch count (a tile belongs to the part its first batch falls into; one part per block), and inside a part the
+// tiles are listed longest first (per run of 64 tiles), the order in which the block's waves pick them up.
+__global__ __launch_bounds__(256) void pairlist_parts_kernel(const int *__restrict__ tile_start, int tiles,
+                                                             int *__restrict__ part_start)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const long total = tile_start[tiles];
+    auto part_of = [&](int tile) {
+        const long p = total > 0 ? (long)tile_start[tile] * MS3D_PL_PARTS / total : 0;
+        return (int)(p < MS3D_PL_PARTS - 1 ? p : MS3D_PL_PARTS - 1);
+    };
+    const int mine = part_of(t), prev = t > 0 ? part_of(t - 1) : -1;
+    for (int q = prev + 1; q <= mine; q++) part_start[q] = t;
+    if (t == tiles - 1)
+        for (int q = mine + 1; q <= MS3D_PL_PARTS; q++) part_start[q] = tiles;
+}
+
+__global__ __launch_bounds__(64) void pairlist_order_kernel(const int *__restrict__ tile_start,
+                                                            const int *__restrict__ part_start, int *__restrict__ order)
+{
+    const int l = lane_id();
+    const int t0 = part_start[blockIdx.x], t1 = part_start[blockIdx.x + 1];
+    for (int c = t0; c < t1; c += 64) {
+        const int tile = c + l;
+        const bool ok = tile < t1;
+        const int cnt = ok ? tile_start[tile + 1] - tile_start[tile] : -1;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const int cj = __builtin_amdgcn_readlane(cnt, j);
+            rank += (cj > cnt || (cj == cnt && j < l)) ? 1 : 0;
+        }
+        if (ok) order[c + rank] = tile;
+    }
+}
+
 // Offset-major pair lists (the classic in/out index pairs per kernel offset) for the backward-weight kernel:
 // kt_start[k * tiles + tile] = first pair of (offset k, 64-row tile), pairs in ascending output row inside it.
 template <int KT>
@@ -393,6 +433,9 @@ int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_do
 
 int ms3d_kmap_pairlist_tiles(int Vout) { return ms3d_divup(Vout, MS3D_PL_ROWS); }
 
+// ints of the tile_start array: tiles + 1 batch offsets, part_start[MS3D_PL_PARTS + 1], order[tiles]
+int ms3d_kmap_pairlist_header_ints(int Vout) { return 2 * ms3d_divup(Vout, MS3D_PL_ROWS) + 1 + MS3D_PL_PARTS + 1; }
+
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout)
 {
     // every (tile, offset) group pads by < 16 entries
@@ -415,6 +458,11 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
     MS3D_LAUNCH_CHECK();
     int rc = ms3d_exclusive_scan_i32(tile_start, tile_start, tiles + 1, nullptr, workspace, stream);
     if (rc) return rc;
+    int *part_start = tile_start + tiles + 1, *order = part_start + MS3D_PL_PARTS + 1;
+    pairlist_parts_kernel<<<ms3d_divup(tiles, 256), 256, 0, stream>>>(tile_start, tiles, part_start);
+    MS3D_LAUNCH_CHECK();
+    pairlist_order_kernel<<<MS3D_PL_PARTS, 64, 0, stream>>>(tile_start, part_start, order);
+    MS3D_LAUNCH_CHECK();
     if (K <= 8)
         pairlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
     else

@@ -455,7 +455,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     f32x4 *sW4 = reinterpret_cast<f32x4 *>(lds);  // [(k*NCH + ch)*NBT + nb][lane] -> the 4 k-steps t of that lane
     const int wslots = p.K * NCH * NBT * 64;
     float *s_part = lds + (size_t)wslots * 4;  // [2*Cout]
-    float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + (size_t)wave_id() * pairlist_wave_floats(NBT);  // [(CR+1)][CW]
+    int *s_next = reinterpret_cast<int *>(s_part + ((2 * p.Cout + 3) & ~3));  // tile pick counter (+ 3 pad: 16-B alignment)
+    float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + 4 + (size_t)wave_id() * pairlist_wave_floats(NBT);  // [(CR+1)][CW]
 
     // weights of this block's column slice: global fragment order [k][ch][t][nb][lane] -> LDS [k][ch][nb][lane][t]
     for (int e = threadIdx.x; e < wslots; e += blockDim.x) {
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         sW4[e] = w;
     }
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (threadIdx.x == 0) *s_next = waves;
     for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
     for (int e = l; e < (CR + 1) * F4; e += 64) reinterpret_cast<f32x4 *>(acc_t)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -476,11 +478,11 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     const int per_xcd = (nblk + 7) / 8;
     int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // blocks of one XCD take neighbouring tiles
     if (nblk % 8 != 0) vb = blockIdx.x;
-    const int total_waves = nblk * waves;
-    const int chunk = (p.ntiles + total_waves - 1) / total_waves;  // p.ntiles counts CR-row tiles here
-    const int wglobal = vb * waves + wave_id();
-    const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
-
+    // one part of the list per block (near-equal batch counts, see pairlist_parts_kernel); the block's waves pick the
+    // part's tiles longest first off an LDS counter (the first `waves` picks are static)
+    const int *__restrict__ part_start = p.pl_tile_start + p.ntiles + 1;  // p.ntiles counts CR-row tiles here
+    const int *__restrict__ order = part_start + MS3D_PL_PARTS + 1;
+    const int t0 = part_start[vb], nmine = part_start[vb + 1] - t0;
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};  // per-lane column sums (columns 4*(l % F4)..+3)
     const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
     const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
@@ -493,7 +495,11 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         pre_sh[ch] = p.pre_scale ? *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int tile = t_begin; tile < t_end; tile++) {
+    int slot = wave_id();
+    while (slot < nmine) {
+        int next_slot = 0;
+        if (l == 0) next_slot = atomicAdd(s_next, 1);  // requested now, consumed after the tile
+        const int tile = __builtin_amdgcn_readfirstlane(order[t0 + slot]);
         const int row0 = tile * CR;
         const int b_begin = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile]);
         const int b_end = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile + 1]);
@@ -597,6 +603,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         // the dummy row collected the pad products; clear it with the rest
         if (l < F4) reinterpret_cast<f32x4 *>(acc_t + CR * CW)[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
+        slot = __builtin_amdgcn_readfirstlane(next_slot);
     }
     if (with_partial) {
 #pragma unroll
@@ -1260,7 +1267,11 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
     if (with_pairlist && pairlist_shape_ok(Vout, K, Cin, Cout)) {
         // column split (the gathers are repeated per slice) only when the weight image would starve the block of waves
         int nbt = NBtot;
-        const size_t spart = (size_t)((2 * Cout + 3) & ~3) * sizeof(float);
+        const size_t spart = (size_t)(((2 * Cout + 3) & ~3) + 4) * sizeof(float);  // statistics + the tile pick counter
+        static const int env_w = [] {
+            const char *e = getenv("MS3D_PL_W");  // tuning knob: cap on waves per block
+            return e ? atoi(e) : 0;
+        }();
         auto waves_for = [&](int nbt_) {
             const size_t wbytes = (size_t)K * NCH * 4 * nbt_ * 64 * sizeof(float);
             const size_t perwave = pairlist_wave_floats(nbt_) * sizeof(float);
@@ -1270,17 +1281,16 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         int W = waves_for(nbt);
         const int tiles = ms3d_divup(Vout, CR);
         if (W > 16) W = 16;
+        if (env_w > 0 && W > env_w) W = env_w;
         if (W >= 2) {
-            // every CU gets a block; waves sized so that the static tile chunks come out even
-            const int chunk = ms3d_divup(tiles, 256 * W);
-            const int wfill = ms3d_divup(ms3d_divup(tiles, chunk), 256);
+            // one block per part of the list (MS3D_PL_PARTS = one per CU); no more waves than a part has tiles
+            const int wfill = ms3d_divup(tiles, MS3D_PL_PARTS);
             if (W > wfill) W = wfill < 2 ? 2 : wfill;
             g.pairlist = true;
             g.ny = NBtot / nbt;
             g.nbt = nbt;
             g.threads = W * 64;
-            g.nblk = ms3d_divup(tiles, W);
-            if (g.nblk > 256) g.nblk = 256;
+            g.nblk = MS3D_PL_PARTS;
             g.G = K;
             g.lds = (size_t)K * NCH * 4 * nbt * 64 * sizeof(float) + spart + (size_t)W * pairlist_wave_floats(nbt) * sizeof(float);
             g.ok = true;

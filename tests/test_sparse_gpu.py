@@ -264,7 +264,18 @@ def test_pair_lists_bit_exact(be, oracle, K):
     # tile-major: per (tile, k) group padded to 16
     nb = (cnt.T + 15) // 16                                  # [tiles, K]
     want_ts = np.concatenate([[0], np.cumsum(nb.sum(1))])
-    assert np.array_equal(tile_start.cpu().numpy(), want_ts)
+    ts_host = tile_start.cpu().numpy()
+    assert np.array_equal(ts_host[:tiles + 1], want_ts)
+    # schedule behind the offsets: 256 parts of near-equal batch count, tiles of a part longest first (runs of 64)
+    assert ts_host.size == 2 * tiles + 1 + 257
+    part_start, order = ts_host[tiles + 1: tiles + 258], ts_host[tiles + 258:]
+    want_part = np.minimum(want_ts[:-1] * 256 // want_ts[-1], 255)
+    assert np.array_equal(part_start, np.searchsorted(want_part, np.arange(257), side="left"))
+    per_tile = np.diff(want_ts)
+    for q in range(256):
+        for c in range(part_start[q], part_start[q + 1], 64):
+            e = min(c + 64, part_start[q + 1])
+            assert np.array_equal(order[c:e], c + np.argsort(-per_tile[c:e], kind="stable"))
     ent = entries[:16 * int(want_ts[-1])].cpu().numpy()
     starts = 16 * (want_ts[:-1, None] + np.cumsum(nb, 1) - nb)   # first entry of every (tile, k) group
     for t in rng.integers(0, tiles, 40):
