@@ -438,8 +438,8 @@ int ms3d_kmap_pairlist_header_ints(int Vout) { return 2 * ms3d_divup(Vout, MS3D_
 
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout)
 {
-    // every (tile, offset) group pads by < 16 entries
-    return (size_t)K * ((size_t)Vout + 15 * (size_t)ms3d_divup(Vout, MS3D_PL_ROWS));
+    // every (tile, offset) group pads by < 16 entries; + one group of slack (an empty last tile still reads its first slots)
+    return (size_t)K * ((size_t)Vout + 15 * (size_t)ms3d_divup(Vout, MS3D_PL_ROWS)) + 128;
 }
 
 int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,

@@ -452,6 +452,11 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     const int l = lane_id(), q = l >> 4, jl = l & 15;
     const int waves = blockDim.x >> 6;
     const int nb0 = blockIdx.y * NBT;
+    // Accumulator tile: row-major, but the 16-byte chunk c of row r sits at chunk c ^ ((r / RPL) % F4), RPL = rows per
+    // 256 bytes.  The pairs of a batch hit (mostly neighbouring) rows with the SAME chunk index: unswizzled, rows that
+    // are RPL apart share their 4 banks -- 16 lanes on 4 (NBT = 1) or 2 (NBT = 2) bank groups, a 4..8-way conflict on
+    // every read-modify-write, which is what bounded this kernel.  Swizzled, 16 consecutive rows cover all 64 banks.
+    auto acc_slot = [](int r, int c) { return r * CW + 4 * (c ^ ((r / (16 / F4)) & (F4 - 1))); };
     f32x4 *sW4 = reinterpret_cast<f32x4 *>(lds);  // [(k*NCH + ch)*NBT + nb][lane] -> the 4 k-steps t of that lane
     const int wslots = p.K * NCH * NBT * 64;
     float *s_part = lds + (size_t)wslots * 4;  // [2*Cout]
@@ -470,7 +475,6 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     }
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
     if (threadIdx.x == 0) *s_next = waves;
-    for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
     for (int e = l; e < (CR + 1) * F4; e += 64) reinterpret_cast<f32x4 *>(acc_t)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
@@ -504,11 +508,30 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         const int b_begin = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile]);
         const int b_end = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile + 1]);
         const int2 *__restrict__ tile_entries = entries + (size_t)b_begin * 16;
+        // Entries of a group of CBU batches (16 * CBU pairs): lane L holds pairs L and 64 + L, one coalesced 8-byte load
+        // each, and a batch's 16 entries reach the four quads that need them through the LDS crossbar (ds_bpermute).
+        // The next group's entries are requested before this group's gathers, so the entry round trip is off the
+        // wave's dependent chain (entry -> gather -> MFMA -> accumulate); a batch index past the tile re-reads its last batch.
+        constexpr int EH = CBU / 4;  // 64-pair halves per group
+        const int last_b = max(b_end - b_begin - 1, 0);
+        int2 nxt[EH];
+#pragma unroll
+        for (int h = 0; h < EH; h++) nxt[h] = tile_entries[(unsigned)(min(4 * h + (l >> 4), last_b) * 16 + jl)];
         for (int b0 = b_begin; b0 < b_end; b0 += CBU) {
             int2 ent[CBU];
             f32x4 a[CBU][NCH];
+            int2 cur[EH];
 #pragma unroll
-            for (int u = 0; u < CBU; u++) ent[u] = tile_entries[(unsigned)((min(b0 + u, b_end - 1) - b_begin) * 16 + jl)];
+            for (int h = 0; h < EH; h++) {
+                cur[h] = nxt[h];
+                nxt[h] = tile_entries[(unsigned)(min(b0 - b_begin + CBU + 4 * h + (l >> 4), last_b) * 16 + jl)];
+            }
+#pragma unroll
+            for (int u = 0; u < CBU; u++) {
+                const int src = ((u & 3) * 16 + jl) << 2;
+                ent[u].x = __builtin_amdgcn_ds_bpermute(src, cur[u >> 2].x);
+                ent[u].y = __builtin_amdgcn_ds_bpermute(src, cur[u >> 2].y);
+            }
 #pragma unroll
             for (int u = 0; u < CBU; u++) {
                 // wave-uniform base + 32-bit lane offset (Vin * Cin < 2^32 elements is checked by the launcher): the 64-bit
@@ -530,9 +553,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
                         }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < CBU; u++) {
-                if (b0 + u >= b_end) break;
+            auto multiply_accumulate = [&](int u) {
                 const int k = ent[u].y >> 8, orow = ent[u].y & 255;
                 f32x4 d[NBT];
 #pragma unroll
@@ -552,11 +573,65 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
                 // measured at ~240 cycles per instruction).
 #pragma unroll
                 for (int nb = 0; nb < NBT; nb++) {
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(acc_t + orow * CW + 16 * nb + 4 * q);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(acc_t + acc_slot(orow, 4 * nb + q));
                     f32x4 cur = *dst;
 #pragma unroll
                     for (int r = 0; r < 4; r++) cur[r] += d[nb][r];
                     *dst = cur;
+                }
+            };
+            if (NCH * NBT <= 2 && b0 + CBU <= b_end) {
+                // Full group, one straight-line block (register budget: up to two fragments per batch).  The compiler cannot tell the weight image from the accumulator
+                // tile (both LDS), so it keeps every batch's fragment read behind the previous batch's accumulator
+                // write: read -> 4 dependent MFMAs -> read-modify-write, ~330 cycles per batch in sequence.  Program order
+                // here is: fragments of batch u+1, accumulator rows of batch u, MFMAs of batch u, add, write.
+                f32x4 wn[NCH][NBT];
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) wn[ch][nb] = sW4[(((ent[0].y >> 8) * NCH + ch) * NBT + nb) * 64 + l];
+#pragma unroll
+                for (int u = 0; u < CBU; u++) {
+                    f32x4 w[NCH][NBT];
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++) w[ch][nb] = wn[ch][nb];
+                    if (u + 1 < CBU) {
+                        const int kn = ent[u + 1].y >> 8;
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                            for (int nb = 0; nb < NBT; nb++) wn[ch][nb] = sW4[((kn * NCH + ch) * NBT + nb) * 64 + l];
+                    }
+                    const int orow = ent[u].y & 255;
+                    f32x4 cur[NBT], d[NBT];
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) {
+                        cur[nb] = *reinterpret_cast<f32x4 *>(acc_t + acc_slot(orow, 4 * nb + q));
+                        d[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // the reads above are issued before the (stalling) MFMA chain, not after it
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++)
+                                d[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ch][nb][t], a[u][ch][t], d[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) cur[nb][r] += d[nb][r];
+                        *reinterpret_cast<f32x4 *>(acc_t + acc_slot(orow, 4 * nb + q)) = cur[nb];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < CBU; u++) {
+                    if (b0 + u >= b_end) break;
+                    multiply_accumulate(u);
                 }
             }
         }
@@ -565,7 +640,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
 #pragma unroll
         for (int i = 0; i < F4; i++) {
             const int r = i * (64 / F4) + l / F4;
-            f32x4 *src = reinterpret_cast<f32x4 *>(acc_t + r * CW + 4 * c4);
+            f32x4 *src = reinterpret_cast<f32x4 *>(acc_t + acc_slot(r, c4));
             f32x4 o4 = *src;
             *src = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int row = row0 + r;
@@ -606,14 +681,30 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         slot = __builtin_amdgcn_readfirstlane(next_slot);
     }
     if (with_partial) {
+        // lanes with equal l % F4 hold the same 4 columns: fold them with shuffles, park the wave's 2 x CW sums in its
+        // (now idle) accumulator tile and let 2 * Cout threads add the waves up in wave order.  (LDS float atomics from
+        // every lane cost ~8 us here: 8 instructions per wave with 16 lanes per address, all waves arriving together.)
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            atomicAdd(&s_part[col + t], st1[t]);
-            atomicAdd(&s_part[p.Cout + col + t], st2[t]);
+        for (int m = F4; m < 64; m <<= 1)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                st1[t] += __shfl_xor(st1[t], m, 64);
+                st2[t] += __shfl_xor(st2[t], m, 64);
+            }
+        if (l < F4) {
+            *reinterpret_cast<f32x4 *>(acc_t + 4 * l) = st1;
+            *reinterpret_cast<f32x4 *>(acc_t + CW + 4 * l) = st2;
         }
         __syncthreads();
         float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+        const float *wave0 = s_part + ((2 * p.Cout + 3) & ~3) + 4;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) {
+            const int which = t >= p.Cout, c = t - which * p.Cout - 16 * nb0;  // column inside this block's slice
+            float sum = 0.f;
+            if (c >= 0 && c < CW)
+                for (int w = 0; w < waves; w++) sum += wave0[(size_t)w * pairlist_wave_floats(NBT) + which * CW + c];
+            dst[t] = sum;
+        }
     }
 }
 
