@@ -160,8 +160,11 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
                              size_t workspace_bytes /* >= ms3d_coord_workspace_bytes(1) */, ms3d_stream_t stream);
 
 /* Offset-major pair list of a table (the classic per-offset in/out index pairs) for the backward-weight kernel:
- *   kt_start[K * tiles + 1]  first pair of (offset k, 64-row tile t) at [k * tiles + t]; last = number of pairs
+ *   kt_start[header_ints]    K * tiles + 1 pair offsets: first pair of (offset k, 64-row tile t) at [k * tiles + t],
+ *                            last = number of pairs; then part_start[257] (tile ranges of near-equal pair count, the
+ *                            workgroups of the backward-weight kernel) and the per-tile pair prefix [tiles + 1] it is cut from
  *   entries[2 * pairs]       int2 per pair: (input row, output row), ascending output row inside an offset */
+size_t ms3d_kmap_offsetlist_header_ints(int K, int Vout);
 size_t ms3d_kmap_offsetlist_capacity(int K, int Vout);
 int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, int *entries, void *workspace,
                                size_t workspace_bytes, ms3d_stream_t stream);

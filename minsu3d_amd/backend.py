@@ -428,8 +428,9 @@ class _HipEngine:
             if self.lib.ms3d_kmap_pairlist_wanted(int(K), int(vout)):
                 self.lib.ms3d_kmap_offsetlist_capacity.restype = C.c_size_t
                 cap = self.lib.ms3d_kmap_offsetlist_capacity(int(K), int(vout))
-                tiles = self.lib.ms3d_kmap_pairlist_tiles(int(vout))
-                kt_start = torch.empty(K * tiles + 1, dtype=torch.int32, device=nbr.device)
+                self.lib.ms3d_kmap_offsetlist_header_ints.restype = C.c_size_t
+                kt_start = torch.empty(self.lib.ms3d_kmap_offsetlist_header_ints(int(K), int(vout)), dtype=torch.int32,
+                                       device=nbr.device)
                 entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
                 ws = self._cws(1, nbr.device)
                 _lib.check(self.lib.ms3d_kmap_offsetlist_build(_lib.ptr(nbr), int(K), int(vout), _lib.ptr(kt_start),

@@ -306,6 +306,18 @@ __global__ __launch_bounds__(64) void pairlist_order_kernel(const int *__restric
     }
 }
 
+// pairs per 64-row tile over all offsets, from the scanned kt_start of an offset-major list (input of the part cut)
+__global__ __launch_bounds__(256) void offsetlist_tile_totals_kernel(const int *__restrict__ kt_start, int K, int tiles,
+                                                                     int *__restrict__ tile_total)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > tiles) return;
+    int n = 0;
+    if (t < tiles)
+        for (int k = 0; k < K; k++) n += kt_start[(size_t)k * tiles + t + 1] - kt_start[(size_t)k * tiles + t];
+    tile_total[t] = n;  // [tiles] = slot of the scan's grand total
+}
+
 // Offset-major pair lists (the classic in/out index pairs per kernel offset) for the backward-weight kernel:
 // kt_start[k * tiles + tile] = first pair of (offset k, 64-row tile), pairs in ascending output row inside it.
 template <int KT>
@@ -471,6 +483,13 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
     return 0;
 }
 
+// ints of the kt_start array: K * tiles + 1 pair offsets, part_start[MS3D_PL_PARTS + 1], pair prefix per tile [tiles + 1]
+size_t ms3d_kmap_offsetlist_header_ints(int K, int Vout)
+{
+    const size_t tiles = ms3d_divup(Vout > 0 ? Vout : 0, MS3D_PL_ROWS);
+    return (size_t)K * tiles + 1 + MS3D_PL_PARTS + 1 + tiles + 1;
+}
+
 size_t ms3d_kmap_offsetlist_capacity(int K, int Vout) { return (size_t)K * (size_t)(Vout > 0 ? Vout : 0); }
 
 int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, int *entries, void *workspace,
@@ -493,6 +512,15 @@ int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, i
         offsetlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start, reinterpret_cast<int2 *>(entries));
     else
         offsetlist_fill_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, kt_start, reinterpret_cast<int2 *>(entries));
+    MS3D_LAUNCH_CHECK();
+    // tile ranges of near-equal pair count for the workgroups of the backward-weight kernel (equal ROW ranges differ
+    // ~1.4x in pairs on a scan, and the launch lasts as long as its fullest workgroup)
+    int *part_start = kt_start + (size_t)K * tiles + 1, *tile_prefix = part_start + MS3D_PL_PARTS + 1;
+    offsetlist_tile_totals_kernel<<<ms3d_divup(tiles + 1, 256), 256, 0, stream>>>(kt_start, K, tiles, tile_prefix);
+    MS3D_LAUNCH_CHECK();
+    rc = ms3d_exclusive_scan_i32(tile_prefix, tile_prefix, tiles + 1, nullptr, workspace, stream);
+    if (rc) return rc;
+    pairlist_parts_kernel<<<ms3d_divup(tiles, 256), 256, 0, stream>>>(tile_prefix, tiles, part_start);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

@@ -895,8 +895,9 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     float *s_part = lds;                                                          // [nw][2][NA*256]
     float *s_tile = lds + (size_t)nw * 2 * NA * 256 + (size_t)w * TB * NT * 256;  // [TB][NCH + NBT][16 pairs][16]
     const int tiles = (p.Vout + MS3D_PL_ROWS - 1) / MS3D_PL_ROWS;
-    const int tpb = p.rows_per_block / MS3D_PL_ROWS;  // rows_per_block is a multiple of the tile size here
-    const int t_lo = min(tiles, (int)blockIdx.x * tpb), t_hi = min(tiles, t_lo + tpb);
+    // tile range of this workgroup: 2^rows_per_block consecutive parts of the list's equal-pair-count cut
+    const int *__restrict__ part_start = p.ol_kt_start + (size_t)p.K * tiles + 1;
+    const int t_lo = part_start[blockIdx.x << p.rows_per_block], t_hi = part_start[(blockIdx.x + 1) << p.rows_per_block];
     if (w == 0) {
         const int kk = min(l, p.K - 1);
         const int lo = p.ol_kt_start[(size_t)kk * tiles + t_lo], hi = p.ol_kt_start[(size_t)kk * tiles + t_hi];
@@ -1516,9 +1517,17 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     const int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
     const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
-    const int gran = use_list ? MS3D_PL_ROWS : 16;
-    p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), gran) * gran;
-    const int nblk = ms3d_divup(Vout, p.rows_per_block);
+    int nblk;
+    if (use_list) {
+        // workgroups = the list's MS3D_PL_PARTS equal-pair-count parts, merged in pairs until there are <= chunks
+        int shift = 0;
+        while ((MS3D_PL_PARTS >> shift) > chunks) shift++;
+        p.rows_per_block = shift;  // the list kernel reads this field as the merge shift
+        nblk = MS3D_PL_PARTS >> shift;
+    } else {
+        p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
+        nblk = ms3d_divup(Vout, p.rows_per_block);
+    }
     const int nb = p.NBtot;
     if (nb > 14) return MS3D_E_UNSUPPORTED;
     int rc;

@@ -256,11 +256,18 @@ def test_pair_lists_bit_exact(be, oracle, K):
     kk, rows = np.nonzero(nbr >= 0)
     want_pairs = np.stack([nbr[kk, rows], rows], 1).astype(np.int32)
     n = want_pairs.shape[0]
-    assert int(kt_start[-1]) == n
+    kt_host = kt_start.cpu().numpy()
+    assert kt_host.size == K * tiles + 1 + 257 + tiles + 1 and int(kt_host[K * tiles]) == n
     assert np.array_equal(pairs[:n].cpu().numpy(), want_pairs)
     cnt = np.zeros((K, tiles), np.int64)
     np.add.at(cnt, (kk, rows // 64), 1)
-    assert np.array_equal(kt_start.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt.reshape(-1))]))
+    assert np.array_equal(kt_host[:K * tiles + 1], np.concatenate([[0], np.cumsum(cnt.reshape(-1))]))
+    # behind the offsets: 256 tile ranges of near-equal pair count (workgroups of the backward-weight kernel) and the
+    # per-tile pair prefix they are cut from
+    prefix = np.concatenate([[0], np.cumsum(cnt.sum(0))])
+    assert np.array_equal(kt_host[K * tiles + 258:], prefix)
+    want_part = np.minimum(prefix[:-1] * 256 // prefix[-1], 255)
+    assert np.array_equal(kt_host[K * tiles + 1: K * tiles + 258], np.searchsorted(want_part, np.arange(257), side="left"))
     # tile-major: per (tile, k) group padded to 16
     nb = (cnt.T + 15) // 16                                  # [tiles, K]
     want_ts = np.concatenate([[0], np.cumsum(nb.sum(1))])
