@@ -306,16 +306,32 @@ __global__ __launch_bounds__(64) void pairlist_order_kernel(const int *__restric
     }
 }
 
-// pairs per 64-row tile over all offsets, from the scanned kt_start of an offset-major list (input of the part cut)
-__global__ __launch_bounds__(256) void offsetlist_tile_totals_kernel(const int *__restrict__ kt_start, int K, int tiles,
-                                                                     int *__restrict__ tile_total)
+// Part cut of an offset-major list.  kt_start is an exclusive scan in (offset, tile) order, so the number of pairs in
+// tiles [0, t) over all offsets is sum_k (kt_start[k * tiles + t] - kt_start[k * tiles]): no second scan.  Writes that
+// per-tile prefix ([tiles + 1]) and part_start (same rule as pairlist_parts_kernel: a tile belongs to the part its
+// first pair falls into).
+__global__ __launch_bounds__(256) void offsetlist_parts_kernel(const int *__restrict__ kt_start, int K, int tiles,
+                                                               int *__restrict__ part_start, int *__restrict__ tile_prefix)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > tiles) return;
-    int n = 0;
-    if (t < tiles)
-        for (int k = 0; k < K; k++) n += kt_start[(size_t)k * tiles + t + 1] - kt_start[(size_t)k * tiles + t];
-    tile_total[t] = n;  // [tiles] = slot of the scan's grand total
+    const long total = kt_start[(size_t)K * tiles];
+    long mine = 0, prev = 0;
+    for (int k = 0; k < K; k++) {
+        const int base = kt_start[(size_t)k * tiles];
+        mine += kt_start[(size_t)k * tiles + t] - base;
+        if (t > 0) prev += kt_start[(size_t)k * tiles + t - 1] - base;
+    }
+    tile_prefix[t] = (int)mine;
+    if (t == tiles) return;
+    auto part_of = [&](long first) {
+        const long p = total > 0 ? first * MS3D_PL_PARTS / total : 0;
+        return (int)(p < MS3D_PL_PARTS - 1 ? p : MS3D_PL_PARTS - 1);
+    };
+    const int q1 = part_of(mine), q0 = t > 0 ? part_of(prev) : -1;
+    for (int q = q0 + 1; q <= q1; q++) part_start[q] = t;
+    if (t == tiles - 1)
+        for (int q = q1 + 1; q <= MS3D_PL_PARTS; q++) part_start[q] = tiles;
 }
 
 // Offset-major pair lists (the classic in/out index pairs per kernel offset) for the backward-weight kernel:
@@ -516,11 +532,7 @@ int ms3d_kmap_offsetlist_build(const int *nbr, int K, int Vout, int *kt_start, i
     // tile ranges of near-equal pair count for the workgroups of the backward-weight kernel (equal ROW ranges differ
     // ~1.4x in pairs on a scan, and the launch lasts as long as its fullest workgroup)
     int *part_start = kt_start + (size_t)K * tiles + 1, *tile_prefix = part_start + MS3D_PL_PARTS + 1;
-    offsetlist_tile_totals_kernel<<<ms3d_divup(tiles + 1, 256), 256, 0, stream>>>(kt_start, K, tiles, tile_prefix);
-    MS3D_LAUNCH_CHECK();
-    rc = ms3d_exclusive_scan_i32(tile_prefix, tile_prefix, tiles + 1, nullptr, workspace, stream);
-    if (rc) return rc;
-    pairlist_parts_kernel<<<ms3d_divup(tiles, 256), 256, 0, stream>>>(tile_prefix, tiles, part_start);
+    offsetlist_parts_kernel<<<ms3d_divup(tiles + 1, 256), 256, 0, stream>>>(kt_start, K, tiles, part_start, tile_prefix);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
