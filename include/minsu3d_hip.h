@@ -195,6 +195,11 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
  * (sum, sum of squares) of the OUTPUT rows (after the residual add) -> feed ms3d_bn_finalize, no extra pass. */
 int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
                                   ms3d_stream_t stream);
+/* Both images of n layers in ONE launch (a U-Net re-lays ~90 weight tensors per step, ~5 us of dispatch each).
+ * descs: device array of n 48-byte records {const float *W; float *wf; float *wft; int K, Cin, Cout, mirror_bwd,
+ * block_begin, 0}, block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum. */
+int ms3d_spconv_prep_blocks(int K, int Cin, int Cout);
+int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, ms3d_stream_t stream);
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
                      float *scale, float *shift, ms3d_stream_t stream);
@@ -208,7 +213,8 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
                                 const int *ol_entries, ms3d_stream_t stream);
 /* One-call layer entry points (forward / backward of a fused [BN -> ReLU ->] conv): same kernels as above, enqueued
  * from native code.  wf_buf holds both weight images (ms3d_spconv_wf_floats(K,Cin,Cout)+(K,Cout,Cin) floats) and is
- * kept by the caller between forward and backward; ws: ms3d_spconv_layer_ws_floats() floats of scratch. */
+ * kept by the caller between forward and backward; ws: ms3d_spconv_layer_ws_floats() floats of scratch.
+ * layer_forward with W == NULL skips the re-lay: wf_buf already holds the current images (prep_weights_multi). */
 size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout);
 int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd, int Vout, int K, int Cin, int Cout,
                               int mirror_bwd, const float *pre_scale, const float *pre_shift, int pre_relu,

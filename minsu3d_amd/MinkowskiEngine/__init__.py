@@ -9,5 +9,5 @@ Module/parameter names match ME so reference state_dicts keep their keys (`kerne
 from . import utils  # noqa: F401
 from .tensor import SparseTensor, CoordinateManager, cat  # noqa: F401
 from .modules import (MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,  # noqa: F401
-                      MinkowskiReLU)
+                      MinkowskiReLU, prepare_conv_weights, release_conv_weights)
 from .functional import gather_rows  # noqa: F401  (engine extra: x[idx] with a scatter-add backward)

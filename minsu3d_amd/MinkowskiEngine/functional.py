@@ -27,9 +27,13 @@ class SparseConvFn(torch.autograd.Function):
     def forward(ctx, x, W, gamma, beta, residual, spec, bn, want_stats):
         be = get_backend()
         pre = (bn["scale"], bn["shift"]) if bn is not None else None
+        # weight images laid out for the whole model in one launch at the start of its forward (modules.prepare_conv_weights):
+        # the stamp on the parameter says whether that buffer still holds the current weights
+        ready = getattr(W, "_ms3d_wf", None)
+        ready = ready[0] if (ready is not None and ready[1] == getattr(be, "weight_token", None)) else None
         y, stats, wf_buf = be.conv_layer_forward(x, W.view(spec.K, spec.cin, spec.cout), spec.nbr_fwd, spec.vout, spec.K,
                                                  spec.cin, spec.cout, spec.mirror, pre, bool(bn and bn["relu"]), residual,
-                                                 None, want_stats)
+                                                 None, want_stats, **({"wf_ready": ready} if ready is not None else {}))
         if stats is None:
             stats = x.new_zeros(0)
         ctx.spec, ctx.bn, ctx.wf_buf, ctx.has_res = spec, bn, wf_buf, residual is not None

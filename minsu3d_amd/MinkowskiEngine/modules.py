@@ -2,6 +2,7 @@
 v0.5.4): `kernel` of shape (K, in, out) -- (in, out) for kernel_size 1 -- no bias,
 uniform(-1/sqrt(in*K), +1/sqrt(in*K)); MinkowskiBatchNorm wraps `self.bn = nn.BatchNorm1d`."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -27,6 +28,37 @@ class _ConvBase(nn.Module):
 
     def extra_repr(self):
         return f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
+
+
+def prepare_conv_weights(root):
+    """Lay out the kernel-side images of EVERY convolution weight under `root` in one launch (instead of one ~5 us
+    launch per layer inside each convolution call; ~90 per U-Net step) and stamp the parameters.  The stamp is valid
+    until `release_conv_weights()`: call the pair around a forward pass during which the weights do not change
+    (GeneralModel.__call__ does).  Convolutions called outside such a window lay out their own weights as before.
+    Not part of ME's API."""
+    be = get_backend()
+    if not hasattr(be, "prep_weights_multi") or os.environ.get("MS3D_WEIGHT_MULTI", "1") == "0":
+        return
+    layers = []
+    for m in root.modules():
+        if isinstance(m, _ConvBase) and m.kernel.is_cuda:
+            K, cin, cout = m.kernel_volume, m.in_channels, m.out_channels
+            if m.kernel.dim() == 2:
+                K = 1
+            buf = m.__dict__.get("_wf_buf")
+            if buf is None or buf.device != m.kernel.device:
+                buf = m.__dict__["_wf_buf"] = torch.empty(be.wf_floats(K, cin, cout), dtype=torch.float32, device=m.kernel.device)
+            # same orientation rule as the forward() of the module: 3x3x3 maps mirror their offsets in backward-data
+            layers.append((m.kernel, buf, K, cin, cout, m.kernel_size == 3 and m.stride == 1))
+    be.prep_weights_multi(layers)
+    for w, buf, *_ in layers:
+        w._ms3d_wf = (buf, be.weight_token)
+
+
+def release_conv_weights():
+    be = get_backend()
+    if hasattr(be, "release_weights"):
+        be.release_weights()
 
 
 class MinkowskiConvolution(_ConvBase):

@@ -8,6 +8,7 @@ nothing in this package imports the oracle.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -57,6 +58,8 @@ class HipBackend:
         self.lib = _lib.lib()  # raises HipLibraryError when the .so is absent
         self.ws = _Workspace()
         self.kernel_timer = None  # bench.py installs a KernelTimer to bracket chosen launches with HIP events
+        self.weight_token = 0     # see prep_weights_multi
+        self._prep_table = None
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -527,13 +530,44 @@ class _HipEngine:
             v = cache[k] = fn(*[int(a) for a in key])
         return v
 
+    def wf_floats(self, K, cin, cout):
+        return self._geom("ms3d_spconv_wf_floats", K, cin, cout) + self._geom("ms3d_spconv_wf_floats", K, cout, cin)
+
+    def prep_weights_multi(self, layers):
+        """layers: [(W [K,cin,cout] parameter, wf_buf, K, cin, cout, mirror_bwd)] -> both weight images of every layer in
+        ONE launch; bumps `weight_token`, the stamp that says "the images in these buffers are the current weights"
+        (release_weights() bumps it again).  The descriptor table lives on the device and is rebuilt only when the set
+        of tensors changes."""
+        if not layers:
+            return
+        key = tuple((w.data_ptr(), b.data_ptr(), m) for w, b, _, _, _, m in layers)
+        cached = self._prep_table
+        if cached is None or cached[0] != key:
+            rec = np.zeros(len(layers), dtype=np.dtype([("W", "<u8"), ("wf", "<u8"), ("wft", "<u8"), ("K", "<i4"),
+                                                         ("Cin", "<i4"), ("Cout", "<i4"), ("mirror", "<i4"),
+                                                         ("begin", "<i4"), ("pad", "<i4")]))
+            begin = 0
+            for i, (w, b, K, cin, cout, m) in enumerate(layers):
+                assert w.is_contiguous() and w.dtype == torch.float32 and b.numel() >= self.wf_floats(K, cin, cout)
+                rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
+                          K, cin, cout, int(bool(m)), begin, 0)
+                begin += self.lib.ms3d_spconv_prep_blocks(int(K), int(cin), int(cout))
+            table = torch.from_numpy(rec.view(np.uint8).copy()).to(layers[0][0].device)
+            cached = self._prep_table = (key, table, begin)
+        _lib.check(self.lib.ms3d_spconv_prep_weights_multi(_lib.ptr(cached[1]), len(layers), int(cached[2]),
+                                                           _lib.stream_handle()), "ms3d_spconv_prep_weights_multi")
+        self.weight_token += 1
+
+    def release_weights(self):
+        self.weight_token += 1
+
     def conv_layer_forward(self, x, W3, nbr_fwd, vout, K, cin, cout, mirror_bwd, pre, pre_relu, residual, bias,
-                           want_stats):
-        """-> (y, stats or None, wf_buf) ; wf_buf carries both weight images to the backward call"""
+                           want_stats, wf_ready=None):
+        """-> (y, stats or None, wf_buf) ; wf_buf carries both weight images to the backward call.  wf_ready: a buffer
+        that already holds the current images (prep_weights_multi) -- the per-layer re-lay launch is skipped."""
         x = self._dev(x)
         dev = x.device
-        nwf = self._geom("ms3d_spconv_wf_floats", K, cin, cout) + self._geom("ms3d_spconv_wf_floats", K, cout, cin)
-        wf_buf = torch.empty(nwf, dtype=torch.float32, device=dev)
+        wf_buf = wf_ready if wf_ready is not None else torch.empty(self.wf_floats(K, cin, cout), dtype=torch.float32, device=dev)
         y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
         stats = None
         pl = self.pairlist(nbr_fwd, K, vout)
@@ -545,7 +579,7 @@ class _HipEngine:
         tok = timer.begin("spconv_fwd", K, cin, cout, nbr_fwd) if timer is not None else None
         ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
         _lib.check(self._fast("ms3d_spconv_layer_forward")(
-            _p(x), _p(self._dev(W3)), _p(nbr_fwd), int(vout), int(K), int(cin), int(cout),
+            _p(x), _p(None if wf_ready is not None else self._dev(W3)), _p(nbr_fwd), int(vout), int(K), int(cin), int(cout),
             int(bool(mirror_bwd)), _p(_f32(ps)), _p(_f32(pb)), int(bool(pre_relu)), _p(_f32(residual)),
             _p(_f32(bias)), _p(wf_buf), _p(y), _p(stats), _p(pl[0]), _p(pl[1]),
             ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")

@@ -99,6 +99,47 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
     }
 }
 
+// Both images (forward, backward-data) of MANY layers in one launch: the per-layer launch is ~5 us of dispatch for a few
+// KB of work, and a U-Net has ~90 of them per step.  descs[i].block_begin = first workgroup of layer i.
+struct PrepDesc {
+    const float *W;   // [K][Cin][Cout]
+    float *wf, *wft;  // forward image, backward-data image (transposed, offsets mirrored if mirror_bwd)
+    int K, Cin, Cout, mirror_bwd, block_begin, pad;
+};
+static_assert(sizeof(PrepDesc) == 48, "layout shared with the host-side descriptor table");
+
+__global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc *__restrict__ descs, int n)
+{
+    int lo = 0, hi = n - 1;  // last layer with block_begin <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PrepDesc d = descs[lo];
+    const int NCH = (d.Cin + 15) / 16, NB = (d.Cout + 15) / 16;
+    const long total = (long)d.K * NCH * 4 * NB * 64;  // same element count for both images
+    const long o = (long)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int lane = (int)(o & 63), q = lane >> 4, jl = lane & 15;
+    {
+        long r = o >> 6;
+        const int nb = (int)(r % NB); r /= NB;
+        const int t = (int)(r & 3); r >>= 2;
+        const int ch = (int)(r % NCH), k = (int)(r / NCH);
+        const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;
+        d.wf[o] = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
+    }
+    {
+        long r = o >> 6;
+        const int nb = (int)(r % NCH); r /= NCH;  // the transposed operator: NCH2 = NB, NBtot2 = NCH
+        const int t = (int)(r & 3); r >>= 2;
+        const int ch = (int)(r % NB), k = (int)(r / NB);
+        const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;  // c < Cout, j < Cin
+        const int ks = d.mirror_bwd ? (d.K - 1 - k) : k;
+        d.wft[o] = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ forward / backward-data
 constexpr int OG = 9;  // offsets processed together: 9 neighbour indices, then 9 row gathers in flight per wave (7 measured equal, 14 spills)
 
@@ -1297,6 +1338,20 @@ int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int 
     return 0;
 }
 
+// the same for n layers in one launch; descs = device array of {W, wf, wft, K, Cin, Cout, mirror_bwd, block_begin, 0}
+// (48 bytes each, block_begin = running sum of ms3d_spconv_prep_blocks), total_blocks = sum over the layers
+int ms3d_spconv_prep_blocks(int K, int Cin, int Cout)
+{
+    return (int)(((long)K * ms3d_divup(Cin, 16) * 4 * ms3d_divup(Cout, 16) * 64 + 255) / 256);
+}
+int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, ms3d_stream_t stream)
+{
+    if (n <= 0 || total_blocks <= 0) return 0;
+    prep_weights_multi_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const PrepDesc *>(descs), n);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // mean / invstd / scale / shift (+ running stats) from per-block (sum, sum of squares) partials written by a conv epilogue
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
@@ -1667,7 +1722,7 @@ int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd
                               ms3d_stream_t stream)
 {
     float *wf = wf_buf, *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
-    int rc = ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream);
+    int rc = W ? ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream) : 0;  // W == NULL: wf_buf is current
     if (rc) return rc;
     // optional HIP events bracketing ONLY the convolution kernel, on the stream it is launched on (bench.py roofline)
     if (ev_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));

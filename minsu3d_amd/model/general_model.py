@@ -37,6 +37,15 @@ class GeneralModel(nn.Module):
             opt["fused"] = True   # one launch per step instead of ~30 foreach launches with host gaps in between
         return getattr(importlib.import_module(mod), name)(params=params, **opt)
 
+    def __call__(self, *args, **kwargs):
+        # every convolution weight of the model (backbone, score / refinement nets) is laid out for the kernels in ONE
+        # launch here; the window closes when the forward returns (weights may change afterwards)
+        ME.prepare_conv_weights(self)
+        try:
+            return super().__call__(*args, **kwargs)
+        finally:
+            ME.release_conv_weights()
+
     def forward(self, data_dict):
         return self.backbone(data_dict["voxel_features"], data_dict["voxel_xyz"], data_dict["voxel_point_map"])
 

@@ -132,3 +132,50 @@ def test_softgroup_batched_grouping_equals_per_class_loop_on_device():
     a1, o1 = m._soft_grouping_loop(b, sem, b["grouping_point_offsets"])
     a2, o2 = m._soft_grouping(b, sem, b["grouping_point_offsets"])
     assert o1.numel() > 3 and torch.equal(a1, a2) and torch.equal(o1, o2)
+
+
+def test_weight_images_one_launch_equals_per_layer_and_tracks_updates(monkeypatch):
+    """All convolution weight images of a model are laid out in ONE launch at the start of its forward
+    (ME.prepare_conv_weights).  Two training steps must give exactly the per-layer path's parameters -- i.e. step 2
+    sees the weights Adam wrote in step 1 -- and a convolution called OUTSIDE the model's forward after a weight
+    change must not use a stale image."""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    import minsu3d_amd.MinkowskiEngine as ME
+    backend.set_backend(HipBackend())
+    u = tuple(t.cuda() for t in (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3])))
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((7, 8)).items()}
+
+    def two_steps(multi):
+        monkeypatch.setenv("MS3D_WEIGHT_MULTI", "1" if multi else "0")
+        m = build_model(seed=3).cuda()
+        m.voxelization_rand = u
+        m.eval()                       # fixed BN statistics: no float-atomic noise between the two runs
+        opt = torch.optim.SGD(m.parameters(), lr=5e-2)   # (Adam would turn last-bit gradient noise into +-lr steps)
+        losses = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = sum(m._loss(b, m(b)).values())
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return m, losses
+
+    m1, l1 = two_steps(True)
+    assert any(hasattr(p, "_ms3d_wf") for p in m1.parameters())          # the one-launch path really ran
+    m0, l0 = two_steps(False)
+    assert not any(hasattr(p, "_ms3d_wf") for p in m0.parameters())
+    assert l1[0] == l0[0] and abs(l1[1] - l0[1]) < 1e-5 * abs(l0[1]) and abs(l1[0] - l1[1]) > 1e-3 * abs(l1[0])
+    for (n, p), (_, q) in zip(m1.named_parameters(), m0.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n     # scatter-add atomics in the backward: last-bit noise
+    # outside the model's forward the stamp is void: a changed weight is re-laid by the convolution itself
+    monkeypatch.setenv("MS3D_WEIGHT_MULTI", "1")
+    conv = next(mod for mod in m1.modules() if isinstance(mod, ME.MinkowskiConvolution) and mod.kernel_size == 3
+                and mod.in_channels % 16 == 0)
+    coords = torch.cat([torch.zeros(200, 1, dtype=torch.int32), torch.randint(0, 12, (200, 3), dtype=torch.int32)], 1).unique(dim=0).cuda()
+    x = ME.SparseTensor(features=torch.randn(coords.size(0), conv.in_channels, device="cuda"), coordinates=coords)
+    with torch.no_grad():
+        y0 = conv(x).F.clone()
+        conv.kernel.mul_(2.0)
+        y1 = conv(x).F
+    assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
