@@ -1467,7 +1467,12 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
     } else {
         g.G = (int)((LDS_BUDGET - extra) / per_offset);
         if (g.G > K) g.G = K;
-        int waves = ms3d_divup(ntiles, 64);
+        // the weight groups fill the LDS, so a CU holds one workgroup: as many rounds of 256 workgroups as 16-wave
+        // workgroups need, then the waves per workgroup that spread the tiles evenly over those rounds (3136 tiles:
+        // 242 x 13 waves instead of 196 x 16 with 60 CUs idle; 12544 tiles: 4 rounds of 13 waves instead of 3 + 1/16)
+        static const int env_waves = [] { const char *e = getenv("MS3D_STREAM_WAVES"); return e ? atoi(e) : 0; }();
+        const int rounds = ms3d_divup(ms3d_divup(ntiles, 16), 256);
+        int waves = env_waves > 0 ? env_waves : ms3d_divup(ntiles, rounds * 256);
         waves = waves < 2 ? 2 : (waves > 16 ? 16 : waves);
         g.threads = waves * 64;
         g.nblk = ms3d_divup(ntiles, waves);
