@@ -305,3 +305,25 @@ def test_list_kernels_on_small_and_ragged_levels():
                         "-k", "conv_kernels_vs_oracle or mini_unet"], env=env, cwd=os.path.dirname(here),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_weight_images_of_many_layers_in_one_launch_bit_exact():
+    """ms3d_spconv_prep_weights_multi == ms3d_spconv_prep_weights_pair per layer, for ragged channel counts, K = 1 / 8 / 27
+    and both backward orientations"""
+    from minsu3d_amd.backend import get_backend
+    be = get_backend()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(27, 6, 16, True), (8, 48, 32, False), (1, 16, 16, False), (27, 80, 80, True), (8, 16, 33, False), (27, 16, 16, True)]
+    layers, want = [], []
+    for K, cin, cout, mirror in shapes:
+        W = torch.randn(K, cin, cout, generator=g).cuda()
+        buf = torch.full((be.wf_floats(K, cin, cout),), float("nan"), device="cuda")
+        layers.append((W, buf, K, cin, cout, mirror))
+        want.append(be.prep_weights_pair(W, K, cin, cout, mirror_bwd=mirror))
+    token = be.weight_token
+    be.prep_weights_multi(layers)
+    assert be.weight_token == token + 1
+    for (W, buf, K, cin, cout, _), (wf, wft) in zip(layers, want):
+        assert torch.equal(buf[:wf.numel()], wf) and torch.equal(buf[wf.numel():], wft), (K, cin, cout)
+    be.prep_weights_multi(layers[:2])          # a different set of tensors: the descriptor table is rebuilt
+    assert torch.equal(layers[1][1][:want[1][0].numel()], want[1][0])
