@@ -149,8 +149,9 @@ int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_do
  * valid (input row, output row) pairs are stored contiguously, padded to a multiple of 16 ("batch" = one MFMA group).
  *   tile_start[header_ints] tiles + 1 batch offsets (exclusive scan; last = number of batches), then the schedule of
  *                           the kernels that walk the list: part_start[257] cuts the tiles into 256 parts of near-equal
- *                           batch count (tile t is in part floor(256 * tile_start[t] / batches)), order[tiles] lists
- *                           the tiles of each part by descending batch count (stable, per run of 64 tiles)
+ *                           batch count (tile t is in part floor(256 * tile_start[t] / batches)); then, 16-byte aligned,
+ *                           the pick list int4[tiles] = (tile, first batch, end batch, 0): the tiles of each part by
+ *                           descending batch count (stable, per run of 64 tiles)
  *   entries[2 * 16 * batches]  int2 per pair: (input row, (k << 8) | output row inside the tile); pad = (0, k<<8 | 64)
  * capacity() is the worst case in entries (allocate 8 bytes each); only the used prefix is ever touched. */
 int ms3d_kmap_pairlist_tiles(int Vout);

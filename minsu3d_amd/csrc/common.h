@@ -6,6 +6,8 @@
 #define MS3D_WAVE 64
 #define MS3D_PL_ROWS 64  // output rows per tile of a pair list (ms3d_kmap_pairlist_build)
 #define MS3D_PL_PARTS 256  // a pair list is cut into this many parts of near-equal batch count (one per block of a launch)
+// int offset of the pick list (int4 per tile, 16-byte aligned) inside the tile_start array of a pair list
+#define MS3D_PL_SCHED_OFFSET(tiles) (((tiles) + 1 + MS3D_PL_PARTS + 1 + 3) & ~3)
 
 // Every launcher returns 0 on success or a non-zero hipError_t; nothing ever calls exit().
 #define MS3D_CHECK(expr)                                   \

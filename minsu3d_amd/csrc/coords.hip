@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void pairlist_parts_kernel(const int *__restri
 }
 
 __global__ __launch_bounds__(64) void pairlist_order_kernel(const int *__restrict__ tile_start,
-                                                            const int *__restrict__ part_start, int *__restrict__ order)
+                                                            const int *__restrict__ part_start, int4 *__restrict__ order)
 {
     const int l = lane_id();
     const int t0 = part_start[blockIdx.x], t1 = part_start[blockIdx.x + 1];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void pairlist_order_kernel(const int *__restric
             const int cj = __builtin_amdgcn_readlane(cnt, j);
             rank += (cj > cnt || (cj == cnt && j < l)) ? 1 : 0;
         }
-        if (ok) order[c + rank] = tile;
+        if (ok) order[c + rank] = make_int4(tile, tile_start[tile], tile_start[tile + 1], 0);  // all a wave needs to start the tile
     }
 }
 
@@ -461,8 +461,13 @@ int ms3d_kmap_k2(const int *parent, const int *koff, int Vf, int Vc, int *nbr_do
 
 int ms3d_kmap_pairlist_tiles(int Vout) { return ms3d_divup(Vout, MS3D_PL_ROWS); }
 
-// ints of the tile_start array: tiles + 1 batch offsets, part_start[MS3D_PL_PARTS + 1], order[tiles]
-int ms3d_kmap_pairlist_header_ints(int Vout) { return 2 * ms3d_divup(Vout, MS3D_PL_ROWS) + 1 + MS3D_PL_PARTS + 1; }
+// ints of the tile_start array: tiles + 1 batch offsets, part_start[MS3D_PL_PARTS + 1], (pad to 16 bytes,) the pick
+// list int4[tiles] = (tile, first batch, end batch, 0)
+int ms3d_kmap_pairlist_header_ints(int Vout)
+{
+    const int tiles = ms3d_divup(Vout, MS3D_PL_ROWS);
+    return MS3D_PL_SCHED_OFFSET(tiles) + 4 * tiles;
+}
 
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout)
 {
@@ -486,7 +491,8 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
     MS3D_LAUNCH_CHECK();
     int rc = ms3d_exclusive_scan_i32(tile_start, tile_start, tiles + 1, nullptr, workspace, stream);
     if (rc) return rc;
-    int *part_start = tile_start + tiles + 1, *order = part_start + MS3D_PL_PARTS + 1;
+    int *part_start = tile_start + tiles + 1;
+    int4 *order = reinterpret_cast<int4 *>(tile_start + MS3D_PL_SCHED_OFFSET(tiles));
     pairlist_parts_kernel<<<ms3d_divup(tiles, 256), 256, 0, stream>>>(tile_start, tiles, part_start);
     MS3D_LAUNCH_CHECK();
     pairlist_order_kernel<<<MS3D_PL_PARTS, 64, 0, stream>>>(tile_start, part_start, order);

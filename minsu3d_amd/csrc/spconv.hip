@@ -504,33 +504,58 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     int *s_next = reinterpret_cast<int *>(s_part + ((2 * p.Cout + 3) & ~3));  // tile pick counter (+ 3 pad: 16-B alignment)
     float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + 4 + (size_t)wave_id() * pairlist_wave_floats(NBT);  // [(CR+1)][CW]
 
-    // weights of this block's column slice: global fragment order [k][ch][t][nb][lane] -> LDS [k][ch][nb][lane][t]
-    for (int e = threadIdx.x; e < wslots; e += blockDim.x) {
-        const int lane = e & 63, r = e >> 6;
-        const int nb = r % NBT, kc = r / NBT;  // kc = k*NCH + ch
-        const float *src = p.wf + ((size_t)kc * 4 * p.NBtot + nb0 + nb) * 64 + lane;
-        f32x4 w;
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // blocks of one XCD take neighbouring tiles
+    if (nblk % 8 != 0) vb = blockIdx.x;
+    // one part of the list per block (near-equal batch counts, see pairlist_parts_kernel); the block's waves pick the
+    // part's tiles longest first off an LDS counter (the first `waves` picks are static).  A pick is one 16-byte
+    // descriptor (tile, first batch, end batch); a wave's first descriptor and first group of entries are requested
+    // here, in front of the weight staging, and every later tile's during the tile before it: order -> tile_start ->
+    // entries -> gather were four dependent round trips at the start of every tile.
+    const int *__restrict__ part_start = p.pl_tile_start + p.ntiles + 1;  // p.ntiles counts CR-row tiles here
+    const int4 *__restrict__ picks = reinterpret_cast<const int4 *>(p.pl_tile_start + MS3D_PL_SCHED_OFFSET(p.ntiles));
+    const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
+    constexpr int EH = CBU / 4;  // 64-pair halves per group of CBU batches
+    const int t0 = part_start[vb], nmine = part_start[vb + 1] - t0;
+    int slot = wave_id();
+    auto first_entries = [&](const int4 &d, int2 (&e)[EH]) {
+        const int last = max(d.z - d.y - 1, 0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) w[t] = src[(size_t)t * p.NBtot * 64];
-        sW4[e] = w;
+        for (int h = 0; h < EH; h++)
+            e[h] = entries[(size_t)d.y * 16 + (unsigned)(min(4 * h + (l >> 4), last) * 16 + jl)];
+    };
+    int4 desc = picks[min(t0 + min(slot, max(nmine - 1, 0)), p.ntiles - 1)];  // (an empty part: any valid pick, never used)
+    int2 nxt[EH];
+    first_entries(desc, nxt);
+
+    // weights of this block's column slice: global fragment order [k][ch][t][nb][lane] -> LDS [k][ch][nb][lane][t].
+    // A thread fetches 16 bytes (lanes 4g..4g+3 of step t), the four threads of a quad (t = 0..3) transpose their 4x4
+    // block with two exchange stages, and each stores the 16 bytes of ONE lane's four steps: 4x fewer global loads
+    // than one dword per (lane, step) -- the staging was 4-8 us of every launch (27 ... 55 KB per workgroup).
+    for (int e = threadIdx.x; e < wslots; e += blockDim.x) {
+        const int t = e & 3, g = (e >> 2) & 15, r = e >> 6;
+        const int nb = r % NBT, kc = r / NBT;  // kc = k*NCH + ch
+        f32x4 a = *reinterpret_cast<const f32x4 *>(p.wf + ((size_t)(kc * 4 + t) * p.NBtot + nb0 + nb) * 64 + 4 * g);
+        {
+            const bool odd = t & 1;
+            const float rx = __shfl_xor(odd ? a[0] : a[1], 1, 64), ry = __shfl_xor(odd ? a[2] : a[3], 1, 64);
+            if (odd) { a[0] = rx; a[2] = ry; } else { a[1] = rx; a[3] = ry; }
+        }
+        {
+            const bool hi = t & 2;
+            const float rx = __shfl_xor(hi ? a[0] : a[2], 2, 64), ry = __shfl_xor(hi ? a[1] : a[3], 2, 64);
+            if (hi) { a[0] = rx; a[1] = ry; } else { a[2] = rx; a[3] = ry; }
+        }
+        sW4[e] = a;  // e = r*64 + 4g + t: lane 4g + t of fragment r, steps 0..3
     }
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
     if (threadIdx.x == 0) *s_next = waves;
     for (int e = l; e < (CR + 1) * F4; e += 64) reinterpret_cast<f32x4 *>(acc_t)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    const int nblk = gridDim.x;
-    const int per_xcd = (nblk + 7) / 8;
-    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // blocks of one XCD take neighbouring tiles
-    if (nblk % 8 != 0) vb = blockIdx.x;
-    // one part of the list per block (near-equal batch counts, see pairlist_parts_kernel); the block's waves pick the
-    // part's tiles longest first off an LDS counter (the first `waves` picks are static)
-    const int *__restrict__ part_start = p.pl_tile_start + p.ntiles + 1;  // p.ntiles counts CR-row tiles here
-    const int *__restrict__ order = part_start + MS3D_PL_PARTS + 1;
-    const int t0 = part_start[vb], nmine = part_start[vb + 1] - t0;
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};  // per-lane column sums (columns 4*(l % F4)..+3)
     const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
-    const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
     // fused input BatchNorm(+ReLU): this lane's 4 channels per chunk, loaded once (inside the batch loop the two loads
     // were re-issued and waited for in every chunk)
     f32x4 pre_sc[NCH], pre_sh[NCH];
@@ -540,24 +565,21 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         pre_sh[ch] = p.pre_scale ? *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    int slot = wave_id();
     while (slot < nmine) {
         int next_slot = 0;
-        if (l == 0) next_slot = atomicAdd(s_next, 1);  // requested now, consumed after the tile
-        const int tile = __builtin_amdgcn_readfirstlane(order[t0 + slot]);
+        if (l == 0) next_slot = atomicAdd(s_next, 1);  // consumed right below: the next pick's descriptor is requested now
+        const int tile = __builtin_amdgcn_readfirstlane(desc.x);
         const int row0 = tile * CR;
-        const int b_begin = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile]);
-        const int b_end = __builtin_amdgcn_readfirstlane(p.pl_tile_start[tile + 1]);
+        const int b_begin = __builtin_amdgcn_readfirstlane(desc.y);
+        const int b_end = __builtin_amdgcn_readfirstlane(desc.z);
         const int2 *__restrict__ tile_entries = entries + (size_t)b_begin * 16;
         // Entries of a group of CBU batches (16 * CBU pairs): lane L holds pairs L and 64 + L, one coalesced 8-byte load
         // each, and a batch's 16 entries reach the four quads that need them through the LDS crossbar (ds_bpermute).
         // The next group's entries are requested before this group's gathers, so the entry round trip is off the
         // wave's dependent chain (entry -> gather -> MFMA -> accumulate); a batch index past the tile re-reads its last batch.
-        constexpr int EH = CBU / 4;  // 64-pair halves per group
         const int last_b = max(b_end - b_begin - 1, 0);
-        int2 nxt[EH];
-#pragma unroll
-        for (int h = 0; h < EH; h++) nxt[h] = tile_entries[(unsigned)(min(4 * h + (l >> 4), last_b) * 16 + jl)];
+        next_slot = __builtin_amdgcn_readfirstlane(next_slot);
+        const int4 next_desc = picks[t0 + min(next_slot, nmine - 1)];
         for (int b0 = b_begin; b0 < b_end; b0 += CBU) {
             int2 ent[CBU];
             f32x4 a[CBU][NCH];
@@ -676,6 +698,10 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
                 }
             }
         }
+        // the next tile's first entries: in flight during the epilogue (the loop above left `nxt` with a clamped re-read)
+        slot = next_slot;
+        desc = next_desc;
+        first_entries(desc, nxt);
         __builtin_amdgcn_wave_barrier();
         // ---- epilogue: CR x CW accumulator tile, row-major, 16 B per lane per step
 #pragma unroll
@@ -719,7 +745,6 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         // the dummy row collected the pad products; clear it with the rest
         if (l < F4) reinterpret_cast<f32x4 *>(acc_t + CR * CW)[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
-        slot = __builtin_amdgcn_readfirstlane(next_slot);
     }
     if (with_partial) {
         // lanes with equal l % F4 hold the same 4 columns: fold them with shuffles, park the wave's 2 x CW sums in its
@@ -1424,7 +1449,8 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
             const size_t perwave = pairlist_wave_floats(nbt_) * sizeof(float);
             return wbytes + spart >= LDS_BUDGET ? 0 : (int)((LDS_BUDGET - wbytes - spart) / perwave);
         };
-        while (nbt > 1 && nbt % 2 == 0 && waves_for(nbt) < 8) nbt /= 2;
+        static const int min_waves = [] { const char *e = getenv("MS3D_PL_MIN_WAVES"); return e ? atoi(e) : 8; }();
+        while (nbt > 1 && nbt % 2 == 0 && waves_for(nbt) < min_waves) nbt /= 2;
         int W = waves_for(nbt);
         const int tiles = ms3d_divup(Vout, CR);
         if (W > 16) W = 16;

@@ -274,8 +274,11 @@ def test_pair_lists_bit_exact(be, oracle, K):
     ts_host = tile_start.cpu().numpy()
     assert np.array_equal(ts_host[:tiles + 1], want_ts)
     # schedule behind the offsets: 256 parts of near-equal batch count, tiles of a part longest first (runs of 64)
-    assert ts_host.size == 2 * tiles + 1 + 257
-    part_start, order = ts_host[tiles + 1: tiles + 258], ts_host[tiles + 258:]
+    sched_off = (tiles + 1 + 257 + 3) & ~3                       # pick list: int4 (tile, first batch, end batch, 0), 16-B aligned
+    assert ts_host.size == sched_off + 4 * tiles
+    part_start, picks = ts_host[tiles + 1: tiles + 258], ts_host[sched_off:].reshape(tiles, 4)
+    order = picks[:, 0]
+    assert np.array_equal(picks[:, 1], want_ts[order]) and np.array_equal(picks[:, 2], want_ts[order + 1]) and not picks[:, 3].any()
     want_part = np.minimum(want_ts[:-1] * 256 // want_ts[-1], 255)
     assert np.array_equal(part_start, np.searchsorted(want_part, np.arange(257), side="left"))
     per_tile = np.diff(want_ts)
