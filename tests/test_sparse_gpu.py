@@ -78,9 +78,26 @@ def test_conv_pair_compacted_kernels_vs_oracle(be, oracle, cin, cout, K):
     assert V >= 50000
 
 
-def _check_conv(be, oracle, cin, cout, K, npts, extent):
+def skewed_coords(rng):
+    """a solid 24^3 block (interior voxels have all 27 neighbours: 108 pair batches per 64-row tile) next to 45k isolated
+    voxels (centre pair only: 4 batches per tile): the schedule's parts then hold between 1 and ~25 tiles"""
+    g = np.arange(24, dtype=np.int32)
+    block = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + 2
+    far = np.unique(rng.integers(0, 400, (60000, 3)).astype(np.int32) * 3 + 100, axis=0)[:45000]   # spacing >= 3: no neighbours
+    xyz = np.concatenate([block, far])
+    c = np.concatenate([np.zeros((xyz.shape[0], 1), np.int32), xyz], 1)
+    return c[rng.permutation(c.shape[0])]
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32)])
+def test_pair_list_kernels_on_a_skewed_scene(be, oracle, cin, cout):
+    rng = np.random.default_rng(11)
+    _check_conv(be, oracle, cin, cout, 27, 0, 0, coords=skewed_coords(rng))
+
+
+def _check_conv(be, oracle, cin, cout, K, npts, extent, coords=None):
     rng = np.random.default_rng(cin * 1000 + cout + K)
-    c = surface_coords(rng, 2, npts, extent)
+    c = surface_coords(rng, 2, npts, extent) if coords is None else coords
     V = c.shape[0]
     if K == 27:
         nbr = oracle.kmap_k3(c, 1)
@@ -236,11 +253,12 @@ def test_mini_unet_eval_mode_backward_hip_vs_torch(be):
         backend.set_backend(prev)
 
 
-@pytest.mark.parametrize("K", [27, 8])
-def test_pair_lists_bit_exact(be, oracle, K):
-    """tile-major (forward) and offset-major (backward-weight) pair lists vs a numpy restatement of their definition"""
+@pytest.mark.parametrize("K,scene", [(27, "surface"), (8, "surface"), (27, "skewed")])
+def test_pair_lists_bit_exact(be, oracle, K, scene):
+    """tile-major (forward) and offset-major (backward-weight) pair lists, schedules included, vs a numpy restatement of
+    their definition; the skewed scene has parts of 1 tile next to parts of ~25"""
     rng = np.random.default_rng(K)
-    c = surface_coords(rng, 2, 200000 if K == 27 else 600000, 300 if K == 27 else 400)
+    c = skewed_coords(rng) if scene == "skewed" else surface_coords(rng, 2, 200000 if K == 27 else 600000, 300 if K == 27 else 400)
     if K == 27:
         nbr = oracle.kmap_k3(c, 1).T.copy()                  # [K, V]
     else:
