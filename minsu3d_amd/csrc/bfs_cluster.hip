@@ -32,7 +32,6 @@
 namespace {
 
 constexpr int BFS_THREADS = 1024;  // largest replay workgroup (LDS arrays are sized for it); the launch picks 512 or 1024
-constexpr int BFS_WAVES = BFS_THREADS / 64;
 constexpr int INT_BIG = 0x7fffffff;
 
 struct Thr {
