@@ -31,7 +31,6 @@
 
 namespace {
 
-constexpr int BFS_THREADS = 1024;  // largest replay workgroup (LDS arrays are sized for it); the launch picks 512 or 1024
 constexpr int INT_BIG = 0x7fffffff;
 
 struct Thr {
