@@ -44,10 +44,13 @@ class _Workspace:
         self.buf = {}
 
     def get(self, key, nbytes, device):
-        b = self.buf.get((key, device))
+        # one buffer per purpose AND stream: operators may run concurrently on different streams (PointGroup's two
+        # independent groupings do), and a kernel's scratch must not be shared between them
+        k = (key, device, _lib.stream_handle().value)
+        b = self.buf.get(k)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-            self.buf[(key, device)] = b
+            self.buf[k] = b
         return b
 
 

@@ -2,6 +2,9 @@
 offset-shifted coordinates) -> proposal voxelisation -> ScoreNet -> RoI max-pool -> score.
 Everything from the ball query to the clusters stays on the device (the reference round-trips through
 host memory for its serial BFS, pointgroup.py:41-66)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 import torch.nn as nn
 
@@ -9,6 +12,24 @@ from .. import MinkowskiEngine as ME
 from ..common_ops.functions import common_ops, pointgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
+
+
+_POOL = None
+_SIDE = {}
+
+
+def _worker():
+    global _POOL
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ms3d-grouping")
+    return _POOL
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class PointGroup(GeneralModel):
@@ -52,10 +73,33 @@ class PointGroup(GeneralModel):
         shifted = (xyz + grouping_offsets[object_idxs]).detach().contiguous()
         sem_fg = sem_pred[object_idxs].contiguous()
 
-        p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
-                                       net.cluster.cluster_shift_meanActive)
-        p_orig, o_orig = self._group(xyz.contiguous(), batch_idxs, batch_offsets, sem_fg, object_idxs,
-                                     net.cluster.cluster_meanActive)
+        xyz = xyz.contiguous()
+        if xyz.is_cuda and os.environ.get("MS3D_GROUP_STREAMS", "1") != "0":
+            # The two groupings are independent, and each sizes its outputs on the host twice (ball-query total, cluster
+            # count): run the second one from a worker thread on a side stream, so that one grouping's kernels fill the
+            # other's host round trips (the library calls release the GIL; scratch buffers are per stream).
+            main = torch.cuda.current_stream()
+            side = _side_stream(xyz.device)
+            side.wait_stream(main)
+
+            def second():
+                with torch.cuda.stream(side), torch.no_grad():
+                    return self._group(xyz, batch_idxs, batch_offsets, sem_fg, object_idxs, net.cluster.cluster_meanActive)
+
+            pending = _worker().submit(second)
+            try:
+                p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
+                                               net.cluster.cluster_shift_meanActive)
+            finally:
+                p_orig, o_orig = pending.result()
+                main.wait_stream(side)
+            p_orig.record_stream(main)
+            o_orig.record_stream(main)
+        else:
+            p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
+                                           net.cluster.cluster_shift_meanActive)
+            p_orig, o_orig = self._group(xyz, batch_idxs, batch_offsets, sem_fg, object_idxs,
+                                         net.cluster.cluster_meanActive)
         p_shift[:, 0] += o_orig.size(0) - 1                    # renumber the second proposal set after the first
         proposals_idx = torch.cat((p_orig, p_shift), dim=0)
         proposals_offset = torch.cat((o_orig, o_shift[1:] + o_orig[-1]))
