@@ -54,6 +54,27 @@ class _Workspace:
         return b
 
 
+_POOL = None
+_SIDE = {}
+
+
+def worker():
+    """the one helper thread that runs host-blocking pieces of a step (operators that size their outputs on the host)
+    beside the main thread; the library calls release the GIL"""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ms3d-side")
+    return _POOL
+
+
+def side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class HipBackend:
     name = "hip"
 

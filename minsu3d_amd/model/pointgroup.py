@@ -3,33 +3,15 @@ offset-shifted coordinates) -> proposal voxelisation -> ScoreNet -> RoI max-pool
 Everything from the ball query to the clusters stays on the device (the reference round-trips through
 host memory for its serial BFS, pointgroup.py:41-66)."""
 import os
-from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
+from ..backend import side_stream as _side_stream, worker as _worker
 from ..common_ops.functions import common_ops, pointgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
-
-
-_POOL = None
-_SIDE = {}
-
-
-def _worker():
-    global _POOL
-    if _POOL is None:
-        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ms3d-grouping")
-    return _POOL
-
-
-def _side_stream(device):
-    s = _SIDE.get(device)
-    if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
-    return s
 
 
 class PointGroup(GeneralModel):
