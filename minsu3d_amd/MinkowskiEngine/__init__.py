@@ -7,7 +7,7 @@ gfx950 sparse-voxel engine.  Exactly the 9 symbols the reference uses (SURVEY Ap
 Module/parameter names match ME so reference state_dicts keep their keys (`kernel`, `bn.weight`, ...).
 """
 from . import utils  # noqa: F401
-from .tensor import SparseTensor, CoordinateManager, cat  # noqa: F401
+from .tensor import SparseTensor, CoordinateManager, cat, prefetch_coordinates  # noqa: F401
 from .modules import (MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,  # noqa: F401
                       MinkowskiReLU, prepare_conv_weights, release_conv_weights)
 from .functional import gather_rows  # noqa: F401  (engine extra: x[idx] with a scatter-add backward)

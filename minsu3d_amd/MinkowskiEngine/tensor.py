@@ -8,6 +8,8 @@ a tensor that only records (scale, shift[, relu]); the following convolution app
 input rows, so `Sequential(BN, ReLU, Conv)` is one gather kernel and never materialises the normalised
 activations.  Touching `.features` of such a tensor materialises it (one elementwise kernel).
 """
+import os
+
 import torch
 
 from ..backend import get_backend
@@ -74,13 +76,77 @@ class CoordinateManager:
         return self.coords[ts].size(0)
 
 
+_PREFETCHED = {}   # (data_ptr, shape) of a coordinate tensor -> (future of (manager, cuda event), the tensor itself)
+
+
+def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True):
+    """Input pipelining (not part of ME's API): build everything that depends on the COORDINATES of a batch the next
+    forward will use -- engine row order, the coordinate sets and kernel maps of `n_levels` U-Net levels, their pair
+    lists -- on the helper thread and a side stream, e.g. while the current step's backward pass keeps the GPU busy and
+    the interpreter idle.  `SparseTensor(features, coordinates)` picks the result up when it is given the same tensor.
+    wait_current_stream=False: the coordinates are known to be complete (a resident batch), the side stream need not
+    wait for the work queued on the caller's stream."""
+    if not coordinates.is_cuda or os.environ.get("MS3D_PREFETCH_COORDS", "1") == "0":
+        return
+    key = (coordinates.data_ptr(), tuple(coordinates.shape))
+    if key in _PREFETCHED:
+        return
+    from ..backend import side_stream, worker
+    side = side_stream(coordinates.device)
+    if wait_current_stream:
+        side.wait_stream(torch.cuda.current_stream())
+
+    def build():
+        with torch.cuda.stream(side), torch.no_grad():
+            be = get_backend()
+            cm = CoordinateManager(coordinates.to(torch.int32), spatial_sort=True)
+            cm.prepare(n_levels)
+            ts = 1
+            for lvl in range(n_levels):          # the lists the convolutions of these levels will ask for
+                nbr, v = cm.k3(ts), cm.size(ts)
+                be.pairlist(nbr, 27, v)
+                be.offsetlist(nbr, 27, v)
+                if lvl + 1 < n_levels:
+                    down, up = cm.k2(ts)
+                    vc = cm.size(2 * ts)
+                    be.pairlist(down, 8, vc); be.offsetlist(down, 8, vc)
+                    be.pairlist(up, 8, v); be.offsetlist(up, 8, v)
+                ts *= 2
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return cm, ev
+
+    _PREFETCHED[key] = (worker().submit(build), coordinates)
+
+
+def _take_prefetched(coordinates):
+    pf = _PREFETCHED.pop((coordinates.data_ptr(), tuple(coordinates.shape)), None) if _PREFETCHED else None
+    if pf is None or pf[1] is not coordinates:
+        return None
+    cm, ev = pf[0].result()
+    cur = torch.cuda.current_stream()
+    cur.wait_event(ev)
+    # everything was allocated under the side stream and is used (and eventually freed) under this one
+    held = [cm.perm, cm.inv] + list(cm.coords.values()) + list(cm._k3.values()) + [t for pair in cm._k2.values() for t in pair]
+    for t in list(held):
+        if t is not None:
+            for attr in ("_ms3d_pairlist", "_ms3d_offsetlist"):
+                held.extend(x for x in (getattr(t, attr, None) or ()) if x is not None)
+    for t in held:
+        if t is not None and t.is_cuda:
+            t.record_stream(cur)
+    return cm
+
+
 class SparseTensor:
     def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1,
                  _pending=None, _stats=None):
         if coordinate_manager is None:
             if device is not None:
                 features, coordinates = features.to(device), coordinates.to(device)
-            coordinate_manager = CoordinateManager(coordinates.to(torch.int32), spatial_sort=True)
+            coordinate_manager = _take_prefetched(coordinates) if coordinates.is_cuda else None
+            if coordinate_manager is None:
+                coordinate_manager = CoordinateManager(coordinates.to(torch.int32), spatial_sort=True)
             if coordinate_manager.perm is not None:
                 features = features[coordinate_manager.perm]
         self._F = features

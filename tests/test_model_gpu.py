@@ -179,3 +179,28 @@ def test_weight_images_one_launch_equals_per_layer_and_tracks_updates(monkeypatc
         conv.kernel.mul_(2.0)
         y1 = conv(x).F
     assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
+
+
+def test_prefetched_coordinate_structures_give_the_same_forward():
+    """ME.prefetch_coordinates builds the row order, kernel maps and pair lists of a batch on the helper thread / side
+    stream; the forward that picks them up must equal the one that builds them itself, and a prefetch is used once."""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    import minsu3d_amd.MinkowskiEngine as ME
+    from minsu3d_amd.MinkowskiEngine import tensor as me_tensor
+    backend.set_backend(HipBackend())
+    m = build_model(seed=4).cuda()
+    m.voxelization_rand = (torch.tensor([0.5, 0.5, 0.5]).cuda(), torch.tensor([0.5, 0.5, 0.5]).cuda())
+    m.eval()
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((9, 10)).items()}
+    with torch.no_grad():
+        ref = m(b)
+        ME.prefetch_coordinates(b["voxel_xyz"], m.backbone.n_levels)
+        assert len(me_tensor._PREFETCHED) == 1
+        got = m(b)
+        assert len(me_tensor._PREFETCHED) == 0            # consumed: the next forward builds its own
+        again = m(b)
+    for o in (got, again):
+        assert torch.equal(o["semantic_scores"], ref["semantic_scores"])
+        assert torch.equal(o["point_offsets"], ref["point_offsets"])
+        assert torch.equal(o["proposal_scores"][1], ref["proposal_scores"][1])
