@@ -11,6 +11,8 @@ import os
 import numpy as np
 import torch
 
+from . import MinkowskiEngine as ME
+
 from .evaluation import (GeneralDatasetEvaluator, evaluate_bbox_acc, evaluate_semantic_accuracy,
                          evaluate_semantic_miou, get_gt_bbox, get_gt_instances)
 
@@ -112,11 +114,18 @@ class Trainer:
         for epoch in range(start, max_epochs):
             model.current_epoch = epoch
             total, n = 0.0, 0
-            for batch in self.dm.train_dataloader():
+            batches = iter(self.dm.train_dataloader())
+            batch = next(batches, None)
+            while batch is not None:
+                upcoming = next(batches, None)      # collated (on the GPU) one step ahead
                 opt.zero_grad(set_to_none=True)
                 loss = model.training_step(batch)
+                if upcoming is not None and torch.is_tensor(upcoming.get("voxel_xyz")):
+                    # coordinate-only structures of the next batch, built under this step's backward pass
+                    ME.prefetch_coordinates(upcoming["voxel_xyz"], model.backbone.n_levels)
                 loss.backward()
                 opt.step()
+                batch = upcoming
                 self.global_step += 1
                 total += float(loss.detach())
                 n += 1
