@@ -348,3 +348,32 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
         assert torch.equal(buf[:wf.numel()], wf) and torch.equal(buf[wf.numel():], wft), (K, cin, cout)
     be.prep_weights_multi(layers[:2])          # a different set of tensors: the descriptor table is rebuilt
     assert torch.equal(layers[1][1][:want[1][0].numel()], want[1][0])
+
+
+@pytest.mark.parametrize("cin,cout,level", [(16, 16, 0), (32, 32, 1), (48, 48, 2)])
+def test_adjoint_identities_at_bench_size(be, cin, cout, level):
+    """size-independent properties at the headline workload's size (4 scenes, ~417k voxels at level 0), no oracle needed:
+    <conv_W(x), g> = <x, conv_W^T(g)> (forward vs backward-data) = <W, dW(x, g)> (backward-weight), and linearity in x"""
+    from minsu3d_amd.data import synthetic
+    from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
+    b = synthetic.to_torch(synthetic.collate([synthetic.make_scene(s) for s in range(4)]), torch.device("cuda", 0))
+    cm = CoordinateManager(b["voxel_xyz"].int().contiguous(), spatial_sort=True)
+    ts = 1
+    for _ in range(level):
+        cm.k2(ts); ts *= 2
+    nbr, V, K = cm.k3(ts), cm.size(ts), 27
+    assert V > 40000
+    g = torch.Generator(device="cuda").manual_seed(level)
+    x = torch.randn(V, cin, device="cuda", generator=g); x2 = torch.randn(V, cin, device="cuda", generator=g)
+    gy = torch.randn(V, cout, device="cuda", generator=g)
+    W = torch.randn(K, cin, cout, device="cuda", generator=g) / (cin * K) ** 0.5
+    wf, wft = be.prep_weights_pair(W, K, cin, cout, mirror_bwd=True)
+    y = be.conv_forward(x, wf, nbr, V, K, cin, cout)
+    dx = be.conv_forward(gy, wft, nbr, V, K, cout, cin)
+    dW = be.conv_backward_weight(x, gy, nbr, V, K, cin, cout)
+    a = torch.dot(y.double().flatten(), gy.double().flatten())
+    assert abs(a - torch.dot(x.double().flatten(), dx.double().flatten())) < 1e-4 * abs(a)
+    assert abs(a - torch.dot(W.double().flatten(), dW.double().flatten())) < 1e-4 * abs(a)
+    y2 = be.conv_forward(x2, wf, nbr, V, K, cin, cout)
+    y12 = be.conv_forward(x + 2 * x2, wf, nbr, V, K, cin, cout)
+    assert rel_err(y12.cpu(), (y + 2 * y2).cpu()) < RTOL
