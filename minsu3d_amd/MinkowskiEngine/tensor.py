@@ -117,6 +117,8 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True):
             return cm, ev
 
     _PREFETCHED[key] = (worker().submit(build), coordinates)
+    while len(_PREFETCHED) > 2:      # prefetched but never used (end of an epoch, a skipped batch): do not pile up
+        _PREFETCHED.pop(next(iter(_PREFETCHED)))
 
 
 def _take_prefetched(coordinates):
