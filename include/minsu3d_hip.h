@@ -76,6 +76,22 @@ int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *co
                                   int *cluster_offsets, int *counts /*[host,2]*/, void *workspace,
                                   size_t workspace_bytes, ms3d_stream_t stream);
 
+/* The same operator with the reference's OWN output contract (hierarchical_aggregation/hierarchical_aggregation.h:14-28,
+ * .cpp:105-184): kept fragments, primaries and -- with set aggregation -- all fragments and the primaries with their
+ * absorbed fragments, each as idxs [rows,2], offsets [n+1], centers [n,5] (x, y, z, class, scene).  Used by the
+ * `COMMON_OPS.hierarchical_aggregation` shim (minsu3d_amd/dropin/COMMON_OPS.py) so that the reference's wrapper
+ * (functions/hais_ops.py:6-79) runs unchanged.  Capacities: N rows / N+1 offsets / 5N floats per list; post_idxs rows
+ * beyond post_offsets[n_primary] are zero.  counts [host,8] = n_kept, kept rows, n_primary, post rows, n_fragment,
+ * fragment rows, primary rows, 0. */
+int ms3d_hierarchical_aggregation_parts(const int16_t *semantic_label, const float *coord_shift, const uint8_t *batch_idxs,
+                                        const int *ball_query_idxs, long n_edges, const int *start_len, int N,
+                                        int capped_hint, int using_set_aggr, const float *point_num_avg /*[host]*/,
+                                        const float *radius_avg /*[host]*/, int nclass, int *kept_idxs, int *kept_offsets,
+                                        float *kept_centers, int *prim_idxs, int *prim_offsets, float *prim_centers,
+                                        int *frag_idxs, int *frag_offsets, float *frag_centers, int *post_idxs,
+                                        int *post_offsets, int *counts /*[host,8]*/, void *workspace,
+                                        size_t workspace_bytes, ms3d_stream_t stream);
+
 /* ---- segment ops: replace sec_mean_cuda / sec_min_cuda / sec_max_cuda, sec_mean/sec_mean.h:15-21
  * (kernels sec_mean.cu:12-79).  sec_mean keeps the reference's sequential divide-then-add order
  * per (proposal, channel), so results are bit-identical. */

@@ -88,9 +88,14 @@ class HipBackend:
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _dev(t):
+        """contiguous device tensor.  The reference's callers hand CPU tensors to the clustering operators
+        (model/pointgroup.py:49-52, hais.py:52-56, softgroup.py:60-63): those are copied to the current GPU -- the
+        computation itself always runs in the HIP library, there is no CPU fallback."""
         if not t.is_cuda:
-            raise _lib.HipLibraryError("HipBackend needs device tensors (got a CPU tensor); "
-                                       "the product path has no CPU fallback")
+            if not torch.cuda.is_available():
+                raise _lib.HipLibraryError("HipBackend needs a GPU (got a CPU tensor and no device is present); "
+                                           "the product path has no CPU fallback")
+            t = t.cuda(non_blocking=True)
         return t.contiguous()
 
     # ------------------------------------------------------------------ ball query
@@ -183,6 +188,39 @@ class HipBackend:
             _lib.ptr(start_len), N, hint, int(bool(using_set_aggr)), pna, ra, ncls, _lib.ptr(out_idx), _lib.ptr(out_off),
             counts, _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_hierarchical_aggregation")
         return out_idx[:counts[1]], out_off[:counts[0] + 1]
+
+    def hierarchical_aggregation_parts(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
+                                       point_num_avg, radius_avg):
+        """the reference's own output contract (hierarchical_aggregation.cpp:105-184) -> dict of device tensors:
+        kept / primary / fragment = (idxs [rows,2], offsets [n+1], centers [n,5]), post = (idxs [F+P rows,2] with a
+        zero tail, offsets [n_primary+1]); fragment and post are None without set aggregation"""
+        hint = int(getattr(start_len, "_ms3d_capped", -1))
+        sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)
+        start_len = self._dev(start_len); batch_idxs = self._dev(batch_idxs)
+        assert sem.dtype == torch.int16 and batch_idxs.dtype == torch.uint8
+        N, dev, ncls = start_len.size(0), start_len.device, len(point_num_avg)
+        pna = (C.c_float * ncls)(*[float(x) for x in point_num_avg])
+        ra = (C.c_float * ncls)(*[float(x) for x in radius_avg])
+        M = max(N, 1)
+        ib = torch.empty((4, M, 2), dtype=torch.int32, device=dev)
+        ob = torch.empty((4, M + 1), dtype=torch.int32, device=dev)
+        cb = torch.empty((3, M, 5), dtype=torch.float32, device=dev)
+        self.lib.ms3d_hais_workspace_bytes.restype = C.c_size_t
+        ws = self.ws.get("hais", self.lib.ms3d_hais_workspace_bytes(N, ncls), dev)
+        counts = (C.c_int * 8)()
+        _lib.check(self.lib.ms3d_hierarchical_aggregation_parts(
+            _lib.ptr(sem), _lib.ptr(cs), _lib.ptr(batch_idxs), _lib.ptr(ball_idx), C.c_long(ball_idx.numel()),
+            _lib.ptr(start_len), N, hint, int(bool(using_set_aggr)), pna, ra, ncls,
+            _lib.ptr(ib[0]), _lib.ptr(ob[0]), _lib.ptr(cb[0]), _lib.ptr(ib[1]), _lib.ptr(ob[1]), _lib.ptr(cb[1]),
+            _lib.ptr(ib[2]), _lib.ptr(ob[2]), _lib.ptr(cb[2]), _lib.ptr(ib[3]), _lib.ptr(ob[3]), counts,
+            _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_hierarchical_aggregation_parts")
+        nk, rk, npr, _rpost, nf, rf, rp = [counts[i] for i in range(7)]
+        out = {"kept": (ib[0, :rk], ob[0, :nk + 1], cb[0, :nk]), "primary": (ib[1, :rp], ob[1, :npr + 1], cb[1, :npr]),
+               "fragment": None, "post": None}
+        if using_set_aggr:
+            out["fragment"] = (ib[2, :rf], ob[2, :nf + 1], cb[2, :nf])
+            out["post"] = (ib[3, :rf + rp], ob[3, :npr + 1])
+        return out
 
     # ------------------------------------------------------------------ segment ops / pools
     def _seg(self, fn_name, inp, offsets):

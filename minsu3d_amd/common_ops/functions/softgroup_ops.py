@@ -7,8 +7,10 @@ from ...backend import get_backend
 
 def sg_bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, threshold, class_id):
     with torch.no_grad():
-        return get_backend().sg_bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, float(threshold),
-                                            int(class_id))
+        out = get_backend().sg_bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, float(threshold),
+                                           int(class_id))
+    # CPU tensors in (the reference's call, model/softgroup.py:60-63) -> results on the CPU like the reference's
+    return out if start_len.is_cuda else tuple(t.cpu() for t in out)
 
 
 def sg_bfs_cluster_batched(group_of_point, thr_per_group, ball_query_idxs, start_len):

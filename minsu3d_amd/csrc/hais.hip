@@ -175,9 +175,74 @@ __global__ void ha_emit_kernel(int ncc, int using_set_aggr, const CC *__restrict
     if (c == 0 && threadIdx.x == 0) out_off[n_kept + totals[2]] = kept_rows_total + totals[3];
 }
 
+
+// ---- the reference's own output contract (hierarchical_aggregation.cpp:105-184): the four lists separately ----
+// flags/ids per component: fragment (kind & 1), kept (kind & 2), primary (kind & 4); one block per component
+__global__ void ha_parts_kernel(int ncc, int using_set_aggr, const CC *__restrict__ cc, const int *__restrict__ cc_idx,
+                                const int *__restrict__ cc_off, const int *__restrict__ absorb_to,
+                                const int *__restrict__ kept_id, const int *__restrict__ kept_off,
+                                const int *__restrict__ prim_id, const int *__restrict__ prim_off /* rows incl. absorbed */,
+                                const int *__restrict__ frag_id, const int *__restrict__ frag_off,
+                                const int *__restrict__ praw_off /* primary rows without absorbed */,
+                                int *kept_idxs, int *kept_offsets, float *kept_centers, int *prim_idxs, int *prim_offsets,
+                                float *prim_centers, int *frag_idxs, int *frag_offsets, float *frag_centers, int *post_idxs,
+                                int *post_offsets)
+{
+    const int c = blockIdx.x;
+    if (c >= ncc) return;
+    const CC me = cc[c];
+    const int s = cc_off[c], size = me.size;
+    auto put = [&](int *idxs, int *offsets, float *centers, int id, int base) {
+        for (int q = threadIdx.x; q < size; q += blockDim.x) {
+            idxs[(base + q) * 2 + 0] = id;
+            idxs[(base + q) * 2 + 1] = cc_idx[(s + q) * 2 + 1];
+        }
+        if (threadIdx.x == 0) {
+            offsets[id + 1] = base + size;  // offsets[0] = 0 is written by the launcher's memset
+            centers[id * 5 + 0] = me.cx;
+            centers[id * 5 + 1] = me.cy;
+            centers[id * 5 + 2] = me.cz;
+            centers[id * 5 + 3] = (float)me.cls;
+            centers[id * 5 + 4] = (float)me.batch;
+        }
+    };
+    if (me.kind & 2) put(kept_idxs, kept_offsets, kept_centers, kept_id[c], kept_off[c]);
+    if (me.kind & 4) put(prim_idxs, prim_offsets, prim_centers, prim_id[c], praw_off[c]);
+    if (using_set_aggr && (me.kind & 1)) put(frag_idxs, frag_offsets, frag_centers, frag_id[c], frag_off[c]);
+    if (using_set_aggr && (me.kind & 4)) {
+        const int id = prim_id[c], base = prim_off[c];
+        for (int q = threadIdx.x; q < size; q += blockDim.x) {
+            post_idxs[(base + q) * 2 + 0] = id;
+            post_idxs[(base + q) * 2 + 1] = cc_idx[(s + q) * 2 + 1];
+        }
+        if (threadIdx.x == 0) {
+            int nfrag = 0, npts = 0, w = base + size;
+            for (int f = 0; f < ncc && nfrag < MAX_FRAG; f++) {
+                if (absorb_to[f] != c) continue;
+                nfrag++;
+                for (int q = cc_off[f]; q < cc_off[f + 1] && npts < MAX_PTS; q++, npts++, w++) {
+                    post_idxs[w * 2 + 0] = id;
+                    post_idxs[w * 2 + 1] = cc_idx[q * 2 + 1];
+                }
+            }
+            post_offsets[id + 1] = w;
+        }
+    }
+}
+
+__global__ void ha_frag_sizes_kernel(int ncc, const CC *__restrict__ cc, int *frag_flag, int *frag_rows, int *praw_rows)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncc) return;
+    const int kind = cc[c].kind;
+    frag_flag[c] = (kind & 1) ? 1 : 0;
+    frag_rows[c] = (kind & 1) ? cc[c].size : 0;
+    praw_rows[c] = (kind & 4) ? cc[c].size : 0;
+}
+
 struct HaWs {
     int *cc_idx, *cc_off, *absorb_to, *kept_flag, *kept_rows, *prim_flag, *prim_rows, *kept_id, *kept_off, *prim_id,
-        *prim_off, *totals;
+        *prim_off, *totals, *frag_flag, *frag_rows, *frag_id, *frag_off, *praw_rows, *praw_off;
     CC *cc;
     float *avg;
     void *scan_ws, *bfs_ws;
@@ -196,7 +261,9 @@ size_t carve(HaWs &w, int N, int nclass, void *base)
     w.absorb_to = (int *)take(nb); w.kept_flag = (int *)take(nb); w.kept_rows = (int *)take(nb);
     w.prim_flag = (int *)take(nb); w.prim_rows = (int *)take(nb); w.kept_id = (int *)take(nb);
     w.kept_off = (int *)take(nb); w.prim_id = (int *)take(nb); w.prim_off = (int *)take(nb);
-    w.totals = (int *)take(sizeof(int) * 4);
+    w.totals = (int *)take(sizeof(int) * 8);
+    w.frag_flag = (int *)take(nb); w.frag_rows = (int *)take(nb); w.frag_id = (int *)take(nb); w.frag_off = (int *)take(nb);
+    w.praw_rows = (int *)take(nb); w.praw_off = (int *)take(nb);
     w.cc = (CC *)take(sizeof(CC) * (size_t)N);
     w.avg = (float *)take(sizeof(float) * 2 * (size_t)(nclass > 0 ? nclass : 1));
     w.scan_ws = take(ms3d_scan_workspace_bytes());
@@ -259,6 +326,71 @@ int ms3d_hierarchical_aggregation(const int16_t *semantic_label, const float *co
     MS3D_CHECK(hipStreamSynchronize(stream));
     counts[0] = h[0] + h[2];
     counts[1] = h[1] + h[3];
+    return 0;
+}
+
+// The reference's own output contract (hierarchical_aggregation.h:14-28, .cpp:105-184): kept fragments, primaries,
+// and -- with set aggregation -- all fragments and the primaries with their absorbed fragments, each as
+// (idxs [rows,2], offsets [n+1], centers [n,5] = x, y, z, class, scene).  Every buffer has capacity N rows /
+// N+1 offsets / N*5 floats; post_idxs rows beyond post_offsets[n_primary] are zero (the reference zero-fills
+// sumNPoint_fragment + sumNPoint_primary rows and the wrapper cuts the tail, functions/hais_ops.py:60-63).
+// counts [host,8]: n_kept, kept rows, n_primary, primary rows (post, incl. absorbed), n_fragment, fragment rows,
+// primary rows (raw), 0.
+int ms3d_hierarchical_aggregation_parts(const int16_t *semantic_label, const float *coord_shift, const uint8_t *batch_idxs,
+                                        const int *ball_query_idxs, long n_edges, const int *start_len, int N,
+                                        int capped_hint, int using_set_aggr, const float *point_num_avg /*[host]*/,
+                                        const float *radius_avg /*[host]*/, int nclass, int *kept_idxs, int *kept_offsets,
+                                        float *kept_centers, int *prim_idxs, int *prim_offsets, float *prim_centers,
+                                        int *frag_idxs, int *frag_offsets, float *frag_centers, int *post_idxs,
+                                        int *post_offsets, int *counts /*[host,8]*/, void *workspace,
+                                        size_t workspace_bytes, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int i = 0; i < 8; i++) counts[i] = 0;
+    MS3D_CHECK(hipMemsetAsync(kept_offsets, 0, sizeof(int), stream));
+    MS3D_CHECK(hipMemsetAsync(prim_offsets, 0, sizeof(int), stream));
+    MS3D_CHECK(hipMemsetAsync(frag_offsets, 0, sizeof(int), stream));
+    MS3D_CHECK(hipMemsetAsync(post_offsets, 0, sizeof(int), stream));
+    if (N <= 0) return 0;
+    HaWs w;
+    if (carve(w, N, nclass, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
+    MS3D_CHECK(hipMemcpyAsync(w.avg, point_num_avg, sizeof(float) * nclass, hipMemcpyHostToDevice, stream));
+    MS3D_CHECK(hipMemcpyAsync(w.avg + nclass, radius_avg, sizeof(float) * nclass, hipMemcpyHostToDevice, stream));
+    int cc_counts[2];
+    int rc = ms3d_bfs_run_internal(0, 0, 0.f, capped_hint, semantic_label, ball_query_idxs, n_edges, start_len, N, w.cc_idx,
+                                   w.cc_off, cc_counts, w.bfs_ws, w.bfs_bytes, stream);
+    if (rc) return rc;
+    const int ncc = cc_counts[0];
+    const int nb = ms3d_divup(ncc, 128);
+    ha_describe_kernel<<<ms3d_divup((long)ncc * 64, 256), 256, 0, stream>>>(ncc, w.cc_idx, w.cc_off, semantic_label,
+                                                                          coord_shift, batch_idxs, w.avg, w.cc);
+    MS3D_LAUNCH_CHECK();
+    if (using_set_aggr) {
+        ha_nearest_kernel<<<nb, 128, 0, stream>>>(ncc, w.cc, w.avg + nclass, w.absorb_to);
+        MS3D_LAUNCH_CHECK();
+        MS3D_CHECK(hipMemsetAsync(post_idxs, 0, sizeof(int) * 2 * (size_t)N, stream));
+    }
+    ha_sizes_kernel<<<nb, 128, 0, stream>>>(ncc, using_set_aggr, w.cc, w.absorb_to, w.kept_flag, w.kept_rows, w.prim_flag,
+                                           w.prim_rows);
+    MS3D_LAUNCH_CHECK();
+    ha_frag_sizes_kernel<<<nb, 128, 0, stream>>>(ncc, w.cc, w.frag_flag, w.frag_rows, w.praw_rows);
+    MS3D_LAUNCH_CHECK();
+    if ((rc = ms3d_exclusive_scan_i32(w.kept_flag, w.kept_id, ncc, w.totals + 0, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.kept_rows, w.kept_off, ncc, w.totals + 1, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.prim_flag, w.prim_id, ncc, w.totals + 2, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.prim_rows, w.prim_off, ncc, w.totals + 3, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.frag_flag, w.frag_id, ncc, w.totals + 4, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.frag_rows, w.frag_off, ncc, w.totals + 5, w.scan_ws, stream))) return rc;
+    if ((rc = ms3d_exclusive_scan_i32(w.praw_rows, w.praw_off, ncc, w.totals + 6, w.scan_ws, stream))) return rc;
+    ha_parts_kernel<<<ncc, 128, 0, stream>>>(ncc, using_set_aggr, w.cc, w.cc_idx, w.cc_off, w.absorb_to, w.kept_id,
+                                            w.kept_off, w.prim_id, w.prim_off, w.frag_id, w.frag_off, w.praw_off, kept_idxs,
+                                            kept_offsets, kept_centers, prim_idxs, prim_offsets, prim_centers, frag_idxs,
+                                            frag_offsets, frag_centers, post_idxs, post_offsets);
+    MS3D_LAUNCH_CHECK();
+    int h[8] = {0};
+    MS3D_CHECK(hipMemcpyAsync(h, w.totals, sizeof(int) * 7, hipMemcpyDeviceToHost, stream));
+    MS3D_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < 7; i++) counts[i] = h[i];
     return 0;
 }
 

@@ -28,8 +28,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_wave)
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_spans_kernel(const int *__restrict__ in, int *__restrict__ out,
-                                                                  int n, int span, int *__restrict__ span_sums)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_spans_kernel(const int *in, int *out /* may alias in */, int n, int span,
+                                                                  int *__restrict__ span_sums)
 {
     __shared__ int s_wave[SCAN_THREADS / 64];
     const long begin = (long)blockIdx.x * span;

@@ -1,0 +1,212 @@
+"""GPU: the reference's callers run unchanged against the drop-in modules.
+
+Each test REPLAYS the call sequence of a reference wrapper / model method (restated here -- the reference tree does
+not exist on the GPU box) with the tensors, devices and ownership rules the reference uses (caller-allocated outputs,
+`resize_` by the callee, CPU tensors for the clustering functions), and checks the result against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def OPS():
+    import minsu3d_amd.dropin as dropin
+    dropin.install()
+    import COMMON_OPS
+    return COMMON_OPS
+
+
+def _scene(seed, n=12000, B=2):
+    rng = np.random.default_rng(seed)
+    c = rng.random((10, 3)) * np.array([3.0, 3.0, 1.0])
+    xyz = (c[rng.integers(0, 10, n)] + rng.standard_normal((n, 3)) * 0.05).astype(np.float32)
+    b = np.sort(rng.integers(0, B, n)).astype(np.uint8)
+    bo = np.concatenate([[0], np.cumsum(np.bincount(b, minlength=B))]).astype(np.int32)
+    sem = rng.integers(2, 5, n).astype(np.int16)
+    return xyz, b, bo, sem
+
+
+def _ballquery(OPS, coords, batch_idxs, batch_offsets, radius, meanActive):
+    """functions/common_ops.py:11-47 (BallQueryBatchP.forward), verbatim control flow"""
+    n = coords.size(0)
+    assert coords.is_contiguous() and coords.is_cuda
+    while True:
+        idx = torch.zeros(n * meanActive, dtype=torch.int32, device="cuda")
+        start_len = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+        nActive = OPS.ballquery_batch_p(coords, batch_idxs, batch_offsets, idx, start_len, n, meanActive, radius)
+        if nActive <= n * meanActive:
+            break
+        meanActive = int(nActive // n + 1)
+    return idx[:nActive], start_len
+
+
+def test_pointgroup_call_sequence(OPS, oracle):
+    """model/pointgroup.py:43-55: ball query on the GPU, `.cpu()`, pg_bfs_cluster on CPU tensors with empty_like outputs
+    (functions/pointgroup_ops.py:8-29)"""
+    xyz, b, bo, sem = _scene(0)
+    idx, start_len = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
+                                torch.from_numpy(bo).cuda(), 0.04, 2)     # meanActive too small: exercises the retry
+    widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(start_len.cpu().numpy(), wsl)
+    semantic_label = torch.from_numpy(sem)                                 # CPU, as semantic_preds_cpu
+    ball_query_idxs, start_len = idx.cpu(), start_len.cpu()
+    N = start_len.size(0)
+    cluster_idxs = torch.empty_like(semantic_label, dtype=torch.int32)
+    cluster_offsets = torch.empty_like(semantic_label, dtype=torch.int32)
+    OPS.pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, cluster_idxs, cluster_offsets, N, 30)
+    want = oracle.pg_bfs_cluster(sem, widx, wsl, 30)
+    assert not cluster_idxs.is_cuda and cluster_idxs.dtype == torch.int32
+    assert cluster_idxs.shape == (want[0].reshape(-1, 2).shape[0], 2) and cluster_offsets.shape == (len(want[1]),)
+    assert np.array_equal(cluster_idxs.numpy(), want[0].reshape(-1, 2)) and np.array_equal(cluster_offsets.numpy(), want[1])
+    # the wrapper of this package with the reference's CPU tensors: same result, returned on the CPU
+    from minsu3d_amd.common_ops.functions import pointgroup_ops
+    a, o = pointgroup_ops.pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, 30)
+    assert not a.is_cuda and torch.equal(a, cluster_idxs) and torch.equal(o, cluster_offsets)
+
+
+def test_softgroup_call_sequence(OPS, oracle):
+    """functions/softgroup_ops.py:18-30: outputs are `ball_query_idxs.new()` (empty), the class means a CPU float tensor"""
+    xyz, b, bo, _ = _scene(1, n=8000, B=1)
+    widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
+    ball_query_idxs, start_len = torch.from_numpy(widx), torch.from_numpy(wsl)     # CPU, model/softgroup.py:60-63
+    mean = [-1.0, 300.0, 2000.0]
+    for class_id in range(3):
+        cluster_idxs = ball_query_idxs.new()
+        cluster_offsets = ball_query_idxs.new()
+        OPS.sg_bfs_cluster(torch.tensor(mean, dtype=torch.float32), ball_query_idxs, start_len, cluster_idxs,
+                           cluster_offsets, start_len.size(0), 0.05, class_id)
+        want = oracle.sg_bfs_cluster(mean, widx, wsl, 0.05, class_id)
+        assert np.array_equal(cluster_idxs.numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+        assert np.array_equal(cluster_offsets.numpy(), want[1])
+
+
+@pytest.mark.parametrize("using_set_aggr", [False, True])
+def test_hais_call_sequence(OPS, oracle, using_set_aggr):
+    """functions/hais_ops.py:22-73 (HierarchicalAggregation.forward) on CPU tensors, post-processing included"""
+    xyz, b, bo, sem = _scene(2)
+    widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
+    semantic_label, coord_shift = torch.from_numpy(sem), torch.from_numpy(xyz)
+    ball_query_idxs, start_len, batch_idxs = torch.from_numpy(widx), torch.from_numpy(wsl), torch.from_numpy(b)
+    point_num_avg = [100.0, 200.0, 400.0, 800.0, 1600.0]
+    radius_avg = [0.1, 0.2, 0.3, 0.5, 0.8]
+    N = start_len.size(0)
+    fragment_idxs = torch.empty_like(semantic_label, dtype=torch.int32)
+    fragment_offsets = torch.empty_like(semantic_label, dtype=torch.int32)
+    fragment_centers = coord_shift.new()
+    cluster_idxs_kept = torch.empty_like(semantic_label, dtype=torch.int32)
+    cluster_offsets_kept = torch.empty_like(semantic_label, dtype=torch.int32)
+    cluster_centers_kept = coord_shift.new()
+    primary_idxs = torch.empty_like(semantic_label, dtype=torch.int32)
+    primary_offsets = torch.empty_like(semantic_label, dtype=torch.int32)
+    primary_centers = coord_shift.new()
+    primary_idxs_post = torch.empty_like(semantic_label, dtype=torch.int32)
+    primary_offsets_post = torch.empty_like(semantic_label, dtype=torch.int32)
+    using_set_aggr_ = int(using_set_aggr)
+    OPS.hierarchical_aggregation(semantic_label, coord_shift, batch_idxs, ball_query_idxs, start_len,
+                                 fragment_idxs, fragment_offsets, fragment_centers,
+                                 cluster_idxs_kept, cluster_offsets_kept, cluster_centers_kept,
+                                 primary_idxs, primary_offsets, primary_centers,
+                                 primary_idxs_post, primary_offsets_post,
+                                 torch.tensor(point_num_avg, dtype=torch.float32, device="cpu"),
+                                 torch.tensor(radius_avg, dtype=torch.float32, device="cpu"),
+                                 N, using_set_aggr_, -1)
+    assert cluster_centers_kept.shape == (cluster_offsets_kept.numel() - 1, 5)
+    assert primary_centers.shape == (primary_offsets.numel() - 1, 5)
+    n_prim_raw_rows = primary_idxs.shape[0]
+    if using_set_aggr_ != 0:
+        assert fragment_centers.shape == (fragment_offsets.numel() - 1, 5)
+        assert primary_idxs_post.shape[0] == fragment_idxs.shape[0] + n_prim_raw_rows     # zero tail, .cpp:166
+        assert not primary_idxs_post[int(primary_offsets_post[-1]):].any()
+        primary_idxs_post = primary_idxs_post[:primary_offsets_post[-1]]
+        primary_idxs = primary_idxs_post
+        primary_offsets = primary_offsets_post
+    cluster_idxs, cluster_offsets = cluster_idxs_kept, cluster_offsets_kept
+    if primary_idxs.shape[0] != 0:
+        primary_idxs[:, 0] += (cluster_offsets.size(0) - 1)
+        primary_offsets += cluster_offsets[-1]
+        cluster_idxs = torch.cat((cluster_idxs, primary_idxs), dim=0)
+        cluster_offsets = torch.cat((cluster_offsets, primary_offsets[1:]))
+    want = oracle.hierarchical_aggregation(sem, xyz, widx, wsl, b, using_set_aggr, point_num_avg, radius_avg)
+    assert np.array_equal(cluster_offsets.numpy(), want[1])
+    assert np.array_equal(cluster_idxs.numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    assert (np.diff(want[1]) > 0).all() and len(want[1]) > 3          # the case is not degenerate
+    # centres: serial f32 sums in BFS order (find_cc's accum_x/y/z), class and scene of the seed
+    ck = cluster_centers_kept.numpy()
+    for c in range(min(ck.shape[0], 20)):
+        members = cluster_idxs_kept[cluster_offsets_kept[c]:cluster_offsets_kept[c + 1], 1].numpy()
+        acc = np.zeros(3, np.float32)
+        for m in members:
+            acc += xyz[m]
+        assert np.array_equal(ck[c, :3], acc / np.float32(len(members)))
+        assert ck[c, 3] == sem[members[0]] and ck[c, 4] == b[members[0]]
+
+
+def test_caller_allocated_outputs(OPS, oracle):
+    """functions/common_ops.py:50-173, softgroup_ops.py:40-77: outputs zero-allocated by the wrapper, filled in place"""
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 300, 64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    S, C_ = int(off[-1]), 16
+    x = rng.standard_normal((S, C_)).astype(np.float32)
+    inp, offsets = torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda()
+    nProposal = offsets.size(0) - 1
+    for name in ("sec_mean", "sec_min", "sec_max"):
+        out = torch.zeros((nProposal, C_), dtype=torch.float32, device="cuda")
+        getattr(OPS, name)(inp, offsets, out, nProposal, C_)
+        assert np.array_equal(out.cpu().numpy(), getattr(oracle, name)(x, off))
+    output_feats = torch.zeros((nProposal, C_), dtype=torch.float32, device="cuda")
+    output_maxidx = torch.zeros((nProposal, C_), dtype=torch.int32, device="cuda")
+    OPS.roipool_fp(inp, offsets, output_feats, output_maxidx, nProposal, C_)
+    wf, wm = oracle.roipool_fp(x, off)
+    assert np.array_equal(output_feats.cpu().numpy(), wf) and np.array_equal(output_maxidx.cpu().numpy(), wm)
+    g = rng.standard_normal((nProposal, C_)).astype(np.float32)
+    d_feats = torch.zeros((S, C_), dtype=torch.float32, device="cuda")
+    OPS.roipool_bp(d_feats, offsets, output_maxidx, torch.from_numpy(g).cuda(), nProposal, C_)
+    assert np.array_equal(d_feats.cpu().numpy(), oracle.roipool_bp(g, off, wm, S))
+    output_feats.zero_()
+    OPS.global_avg_pool_fp(inp, offsets, output_feats, nProposal, C_)
+    assert np.array_equal(output_feats.cpu().numpy(), oracle.global_avg_pool_fp(x, off))
+    d_feats.zero_()
+    OPS.global_avg_pool_bp(d_feats, offsets, torch.from_numpy(g).cuda(), nProposal, C_)
+    assert np.array_equal(d_feats.cpu().numpy(), oracle.global_avg_pool_bp(g, off, S))
+    # IoU family + mask labels
+    N, I = 20000, 23
+    inst = rng.integers(-1, I, N).astype(np.int16)
+    pn = np.bincount(inst[inst >= 0], minlength=I).astype(np.int32)
+    pidx = rng.integers(0, N, S).astype(np.int32)
+    cls = rng.integers(-1, 18, I).astype(np.int16)
+    sig = rng.random(S).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    for name, extra, wextra in (("get_iou", (), ()), ("get_mask_iou_on_cluster", (), ()),
+                                ("get_mask_iou_on_pred", (d(sig),), (sig,))):
+        proposals_iou = torch.zeros((nProposal, I), dtype=torch.float32, device="cuda")
+        getattr(OPS, name)(d(pidx), offsets, d(inst), d(pn), proposals_iou, I, nProposal, *extra)
+        assert np.array_equal(proposals_iou.cpu().numpy(), getattr(oracle, name)(pidx, off, inst, pn, *wextra))
+    iou = torch.zeros((nProposal, I), dtype=torch.float32, device="cuda")
+    OPS.get_iou(d(pidx), offsets, d(inst), d(pn), iou, I, nProposal)
+    mask_label = torch.zeros(pidx.shape, dtype=torch.bool, device="cuda")
+    mask_label_mask = torch.zeros(pidx.shape, dtype=torch.bool, device="cuda")
+    OPS.get_mask_label(d(pidx), offsets, d(inst), d(cls), iou, I, nProposal, -1, 0.05, mask_label, mask_label_mask)
+    wml, wmlm = oracle.get_mask_label(pidx, off, inst, cls, iou.cpu().numpy(), -1, 0.05)
+    assert np.array_equal(mask_label.cpu().numpy(), wml) and np.array_equal(mask_label_mask.cpu().numpy(), wmlm)
+
+
+def test_minkowski_alias_runs_a_reference_shaped_block():
+    """model/module/common.py:21-48 (ResidualBlock) written against `import MinkowskiEngine as ME`"""
+    import minsu3d_amd.dropin as dropin
+    dropin.install()
+    import MinkowskiEngine as ME
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    coords = np.unique(rng.integers(0, 20, (4000, 3)), axis=0).astype(np.int32)
+    coords = np.concatenate([np.zeros((len(coords), 1), np.int32), coords], 1)
+    feats = torch.randn(len(coords), 16, device="cuda")
+    x = ME.SparseTensor(features=feats, coordinates=torch.from_numpy(coords).cuda())
+    block = torch.nn.Sequential(ME.MinkowskiBatchNorm(16), ME.MinkowskiReLU(inplace=True),
+                                ME.MinkowskiConvolution(16, 16, kernel_size=3, dimension=3)).cuda()
+    y = block(x)
+    y += x
+    z = ME.cat(y, x)
+    assert z.F.shape == (len(coords), 32) and torch.equal(z.C, x.C) and torch.isfinite(z.features).all()
