@@ -51,6 +51,22 @@ def test_ballquery_vs_oracle(be, oracle, kind, n, B, radius):
     assert np.array_equal(idx.cpu().numpy(), want_idx)
 
 
+def test_ballquery_collapsed_scene(be, oracle):
+    """every point of a scene inside a few grid cells (a perfectly trained offset branch): neighbourhoods of 20k
+    candidates -- the workgroup sort's global-scratch path -- and every list capped at the 1000 lowest indices"""
+    rng = np.random.default_rng(77)
+    n = 20000
+    xyz = (rng.standard_normal((n, 3)) * 0.004).astype(np.float32)
+    xyz[15000:] += np.float32(0.5)                       # a second, smaller blob (LDS sort path)
+    b = np.zeros(n, np.uint8)
+    bo = np.array([0, n], np.int32)
+    want_idx, want_sl = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+    idx, sl = be.ballquery_batch_p(dev(xyz), dev(b), dev(bo), 0.03, 300)
+    assert want_sl[:, 1].max() == 1000
+    assert np.array_equal(sl.cpu().numpy(), want_sl)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+
+
 def test_ballquery_empty(be):
     idx, sl = be.ballquery_batch_p(torch.zeros((0, 3), device="cuda"), torch.zeros(0, dtype=torch.uint8, device="cuda"),
                                    torch.zeros(2, dtype=torch.int32, device="cuda"), 0.03, 50)
