@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libminsu3d_hip.so")
+# MS3D_LIB: another build of the same library (A/B measurements of a kernel change on one box)
+LIB_PATH = os.environ.get("MS3D_LIB") or os.path.join(_HERE, "lib", "libminsu3d_hip.so")
 _lib = None
 
 

@@ -76,19 +76,28 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b)
     }
 }
 
-__global__ void bfs_init_kernel(int N, int *parent, int *comp_size, int *visited, int *claim, int *cl_size,
-                                int *scratch_seed, int *counters)
+// parent[] starts as a forest already: every point hangs under its smallest label-compatible neighbour (the first
+// entry of its ascending list) when that index is below its own -- one coalesced read per point instead of the CAS
+// storm of 232 k singletons meeting each other in the hook kernel
+__global__ void bfs_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
+                                const int *__restrict__ start_len, int *parent, int *comp_size, int *visited, int *claim,
+                                int *cl_size, int *scratch_seed, int *counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
-        parent[i] = i;
+        int p = i;
+        if (start_len[i * 2 + 1] > 0) {
+            const int j = ball_idx[start_len[i * 2]];
+            if (j < i && (thr.mode != 0 || sem[j] == sem[i])) p = j;
+        }
+        parent[i] = p;
         comp_size[i] = 0;
         visited[i] = 0;
         claim[i] = INT_BIG;
         cl_size[i] = 0;
         scratch_seed[i] = -1;  // "slot not written": the assembly may run before an incomplete expansion is detected
     }
-    if (i < 8) counters[i] = 0;
+    if (i < 16) counters[i] = 0;
 }
 
 // one wave per point, lanes stride its neighbour list.  The root of i is resolved once per wave; an edge whose
@@ -102,30 +111,44 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
                                                        const int *__restrict__ start_len, int *parent)
 {
     const int waves = blockDim.x >> 6;
+    const int l = lane_id();
     for (int i = blockIdx.x * waves + wave_id(); i < N; i += gridDim.x * waves) {
         const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
         if (ln <= 1) continue;  // only itself
         const int lab = thr.mode == 0 ? (int)sem[i] : 0;
         int ri = uf_find(parent, i);
-        for (int t0 = 0; t0 < ln; t0 += 64) {
-            const int t = t0 + lane_id();
-            bool merge = false;
-            int j = i;
-            if (t < ln) {
-                j = ball_idx[st + t];
-                if (j != i && (!symmetric || j < i)) {
-                    if (parent[j] != ri) merge = thr.mode != 0 || (int)sem[j] == lab;  // bfs_cluster.cpp:44
-                }
+        // two 64-edge slices per trip: both index loads, then both parent gathers are in flight together
+        for (int t0 = 0; t0 < ln; t0 += 128) {
+            int j[2], pj[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = t0 + 64 * u + l;
+                j[u] = t < ln ? ball_idx[st + t] : INT_BIG;
             }
-            if (__ballot(merge) == 0ull) continue;
-            // 64 lanes hooking onto the SAME root one CAS at a time serialise (one winner per round); instead every
-            // lane resolves its own neighbour's root, the wave agrees on the smallest root in sight and each distinct
-            // root is hooked under it: the CAS targets are distinct, one round in the common case
-            const int rj = merge ? uf_find(parent, j) : INT_BIG;
-            const int rmin = min(wave_min(rj), ri);
-            if (merge && rj != rmin) uf_union(parent, rj, rmin);
-            if (ri != rmin && lane_id() == 0) uf_union(parent, ri, rmin);
-            ri = uf_find(parent, i);  // refreshed for the next 64 edges
+            // lists are ascending: once a slice starts at or above i the rest of a symmetric graph's list is the other
+            // end's business
+            if (symmetric && __shfl(j[0], 0, 64) >= i) break;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const bool look = j[u] != INT_BIG && j[u] != i && (!symmetric || j[u] < i);
+                pj[u] = look ? parent[j[u]] : ri;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                bool merge = false;
+                if (pj[u] != ri) merge = thr.mode != 0 || (int)sem[j[u]] == lab;  // bfs_cluster.cpp:44
+                if (__ballot(merge) == 0ull) continue;
+                // 64 lanes hooking onto the SAME root one CAS at a time serialise (one winner per round); instead every
+                // lane resolves its own neighbour's root, the wave agrees on the smallest root in sight and each distinct
+                // root is hooked under it: the CAS targets are distinct, one round in the common case
+                const int rj = merge ? uf_find(parent, j[u]) : INT_BIG;
+                const int rmin = min(wave_min(rj), ri);
+                if (merge && rj != rmin) uf_union(parent, rj, rmin);
+                if (ri != rmin && l == 0) uf_union(parent, ri, rmin);
+                const int rnew = uf_find(parent, i);  // refreshed for the next slice
+                if (u == 0 && pj[1] == ri) pj[1] = rnew;  // "already in my set" stays true under the new root
+                ri = rnew;
+            }
         }
     }
 }
@@ -402,14 +425,22 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
 // Chip-wide level-synchronous expansion for SYMMETRIC graphs (no list reached the cap): then a weak component is
 // exactly one cluster, seeded by its root, and all qualifying components can be expanded together by every CU.
 // The frontier array F holds, per level, each component's frontier as one contiguous segment in queue order.
-//   A  : node at frontier position p is assigned its final queue slot and posts atomicMin(claim[j], p) on every
-//        label-compatible neighbour that is not yet visited (visited <=> claim == -1);
-//   U  : per component: done += size of this level's segment, reset the segment bookkeeping;
-//   B1 : cnt[p] = number of edges of p that won (claim[j] == p);  scan -> off[p];
-//   B2 : winners written to F_next[off[p] + rank] in (p, slot) order, marked visited; the first winner of p
-//        lowers its component's next segment start.  Compaction in p order keeps segments contiguous and in
-//        exactly the order in which the serial FIFO BFS would have pushed the nodes.
-// glob counters: [6] |F| of even levels  [7] |F| of odd levels
+// Two launches per level:
+//   claim : node at frontier position p is assigned its final queue slot and posts atomicMin(claim[j], p) on every
+//           label-compatible neighbour that is not yet visited (visited <=> claim == -1).  This is the ONE pass over
+//           the level's edges that gathers per edge; the edges that posted are remembered as one 64-bit mask per
+//           64-edge slice.  The per-component bookkeeping of the NEXT level (queue base, segment start / size: double
+//           buffered by level parity) and the scan state are reset here as well.
+//   win   : single-pass compaction of the winners (claim[j] == p) in (p, slot) order -- the order in which the serial
+//           FIFO BFS would have pushed them: workgroups take tiles of 64 frontier positions off a ticket counter,
+//           test only the masked edges, scan the tile, chain the tile totals by decoupled look-back, and emit the
+//           winners into F_next (marking them visited).  The first winner of p lowers its component's next segment
+//           start; compaction in p order keeps the segments contiguous.
+// Round 1 ran five kernels and a 3-launch scan per level and gathered claim[j] three times per edge.
+// counters: [6] |F| of even levels  [7] |F| of odd levels  [8] tile ticket
+constexpr int WIN_TILE = 16;          // frontier positions per tile
+constexpr int MAX_SLICES = 16;        // 64-edge slices per list (1000-entry cap)
+
 __global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__restrict__ comp_size, int *counters,
                                  int *F0, int *comp_base, int *done, int *seg_start, int *seg_cnt, int *claim)
 {
@@ -426,94 +457,207 @@ __global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__
     claim[r] = -1;  // the seed is visited
 }
 
-__global__ __launch_bounds__(256) void glob_claim_kernel(Thr thr, const int16_t *__restrict__ sem,
-                                                         const int *__restrict__ ball_idx,
-                                                         const int *__restrict__ start_len,
-                                                         const int *__restrict__ root, const int *__restrict__ F,
-                                                         const int *__restrict__ nF_ptr,
-                                                         const int *__restrict__ comp_base,
-                                                         const int *__restrict__ done,
-                                                         const int *__restrict__ seg_start, int *claim,
-                                                         int *scratch_node, int *scratch_seed)
+// first mask slot of a node's list: strictly increasing with the node, never shared between two nodes
+__device__ __forceinline__ long mask_slot(int st, int node) { return (long)(st >> 6) + node; }
+
+__global__ __launch_bounds__(256) void glob_claim_kernel(
+    Thr thr, int level, int exp_flags, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
+    const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ F, int *counters,
+    const int *__restrict__ worklist, const int *__restrict__ comp_base, const int *__restrict__ done_cur, int *done_next,
+    const int *__restrict__ seg_start_cur, int *seg_start_next, const int *__restrict__ seg_cnt_cur, int *seg_cnt_next,
+    int *claim, int *scratch_node, int *scratch_seed, unsigned long long *__restrict__ amask,
+    unsigned long long *tile_status)
 {
-    const int nF = *nF_ptr;
+    const int nF = counters[6 + (level & 1)];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    {
+        const int nwork = counters[0];
+        for (int w = gid; w < nwork; w += gsz) {
+            const int r = worklist[w];
+            done_next[r] = done_cur[r] + seg_cnt_cur[r];
+            seg_start_next[r] = INT_BIG;
+            seg_cnt_next[r] = 0;
+        }
+        const int ntiles = (nF + WIN_TILE - 1) / WIN_TILE;
+        for (int t = gid; t < ntiles; t += gsz) tile_status[t] = 0ull;
+        if (gid == 0) {
+            counters[8] = 0;
+            counters[6 + ((level + 1) & 1)] = 0;
+        }
+    }
     const int waves = blockDim.x >> 6, l = lane_id();
     for (int p = blockIdx.x * waves + wave_id(); p < nF; p += gridDim.x * waves) {
         const int node = F[p];
         const int r = root[node];
         if (l == 0) {
-            const int qpos = comp_base[r] + done[r] + (p - seg_start[r]);
+            const int qpos = comp_base[r] + done_cur[r] + (p - seg_start_cur[r]);
             scratch_node[qpos] = node;
             scratch_seed[qpos] = r;
         }
-        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
+        const int st = start_len[node * 2], ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);  // canonical lists: <= 1000
         const int lab = thr.mode == 0 ? (int)sem[node] : 0;
-        for (int t = l; t < ln; t += 64) {
-            const int j = ball_idx[st + t];
-            // claim first: of a node's ~300 incoming edges all but the first few find it visited or claimed by an
-            // earlier queue position, and then its label is never needed (two random reads per edge -> one)
-            if (claim[j] <= p) continue;  // stale reads are only ever too large -> a redundant atomic
-            if (thr.mode == 0 && (int)sem[j] != lab) continue;
-            atomicMin(&claim[j], p);
+        unsigned long long *am = amask + mask_slot(st, node);
+        // four 64-edge slices per trip: the four index loads, then the four claim gathers are in flight together
+        for (int t0 = 0; t0 < ln; t0 += 256) {
+            int j[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u + l;
+                j[u] = t < ln ? ball_idx[st + t] : -1;
+            }
+            int sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = j[u] >= 0 ? claim[j[u]] : -1;
+                // the label gather rides along with the claim gather (one round trip instead of two in a row; the chain
+                // index -> claim -> label -> coherent re-read -> atomic bounds this kernel, not the request rate)
+                sj[u] = (thr.mode == 0 && j[u] >= 0) ? (int)sem[j[u]] : lab;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t0 + 64 * u >= ln) break;
+                // stale reads are only ever too large -> a redundant atomic
+                bool post = c[u] > p && sj[u] == lab;
+                // the L2 of an XCD does not see the atomics of the other seven: a cached line keeps saying "unclaimed"
+                // long after the node was taken, and every such edge would post an atomic (memory-side, expensive);
+                // a coherent re-read filters them
+                if (post && !(exp_flags & 2)) post = ld_agent(&claim[j[u]]) > p;
+                if (post && !(exp_flags & 1)) atomicMin(&claim[j[u]], p);
+                const unsigned long long m = __ballot(post);
+                if (l == 0) am[(t0 >> 6) + u] = m;
+            }
         }
     }
 }
 
-__global__ void glob_update_kernel(const int *__restrict__ worklist, const int *__restrict__ counters, int *done,
-                                   int *seg_start, int *seg_cnt)
-{
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= counters[0]) return;
-    const int r = worklist[w];
-    done[r] += seg_cnt[r];
-    seg_cnt[r] = 0;
-    seg_start[r] = INT_BIG;
-}
-
-template <bool EMIT>
-__global__ __launch_bounds__(256) void glob_win_kernel(int N, const int *__restrict__ ball_idx,
+__global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__restrict__ ball_idx,
                                                        const int *__restrict__ start_len,
                                                        const int *__restrict__ root, const int *__restrict__ F,
-                                                       const int *__restrict__ nF_ptr, int *claim, int *cnt,
-                                                       const int *__restrict__ off, int *F_next, int *seg_start,
-                                                       int *seg_cnt)
+                                                       int *counters, int *claim,
+                                                       const unsigned long long *__restrict__ amask,
+                                                       unsigned long long *tile_status, int *F_next, int *seg_start_next,
+                                                       int *seg_cnt_next)
 {
-    const int nF = *nF_ptr;
-    const int waves = blockDim.x >> 6, l = lane_id();
-    const int limit = EMIT ? nF : N;  // the count pass also zeroes cnt[] beyond the frontier for the scan
-    for (int p = blockIdx.x * waves + wave_id(); p < limit; p += gridDim.x * waves) {
-        if (p >= nF) {
-            if (l == 0) cnt[p] = 0;
-            continue;
-        }
-        const int node = F[p];
-        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
-        int total = 0;
-        const int base = EMIT ? off[p] : 0;
-        for (int t0 = 0; t0 < ln; t0 += 64) {
-            const int t = t0 + l;
-            int j = -1;
-            bool win = false;
-            if (t < ln) {
-                j = ball_idx[st + t];
-                win = claim[j] == p;
+    __shared__ unsigned long long s_wm[WIN_TILE][MAX_SLICES];
+    __shared__ int s_cnt[WIN_TILE];
+    __shared__ int s_off[WIN_TILE];
+    __shared__ int s_bcast[2];
+    __shared__ int s_node[WIN_TILE], s_st[WIN_TILE], s_ln[WIN_TILE];
+    const int nF = counters[6 + (level & 1)];
+    const int ntiles = (nF + WIN_TILE - 1) / WIN_TILE;
+    const int l = lane_id(), wv = wave_id();
+    constexpr int PER_WAVE = WIN_TILE / 4;
+    constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INCL = 2ull << 62, VAL = (1ull << 62) - 1;
+    if ((int)blockIdx.x >= ntiles) return;  // surplus workgroups leave without touching the ticket counter
+    for (;;) {
+        if (threadIdx.x == 0) s_bcast[0] = atomicAdd(&counters[8], 1);
+        __syncthreads();
+        const int tile = s_bcast[0];
+        if (tile >= ntiles) break;
+        if (threadIdx.x < WIN_TILE) {   // the tile's list headers, all positions at once
+            const int pos = tile * WIN_TILE + threadIdx.x;
+            int node = 0, st = 0, ln = 0;
+            if (pos < nF) {
+                node = F[pos];
+                st = start_len[node * 2];
+                ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);
             }
-            const unsigned long long m = __ballot(win);
-            if (EMIT && win) {
-                F_next[base + total + ballot_rank(m)] = j;
-                claim[j] = -1;  // visited
-            }
-            total += __popcll(m);
+            s_node[threadIdx.x] = node; s_st[threadIdx.x] = st; s_ln[threadIdx.x] = ln;
         }
-        if (l == 0) {
-            if (!EMIT) {
-                cnt[p] = total;
-            } else if (total > 0) {
+        __syncthreads();
+        // ---- pass 1: winners per position, masks kept in LDS
+        for (int k = 0; k < PER_WAVE; k++) {
+            const int q = wv * PER_WAVE + k, pos = tile * WIN_TILE + q;
+            int count = 0;
+            if (pos < nF) {
+                const int node = s_node[q];
+                const int st = s_st[q], ln = s_ln[q];
+                const unsigned long long *am = amask + mask_slot(st, node);
+                const int nsl = (ln + 63) >> 6;
+                const unsigned long long mine = l < nsl ? am[l] : 0ull;   // all slice masks of the list in one load
+                for (int c0 = 0; c0 < nsl; c0 += 4) {   // four slices in flight: index gathers, then claim gathers
+                    int j[4], cl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const unsigned long long m = __shfl(mine, (c0 + u) & 63, 64);
+                        j[u] = (c0 + u < nsl && ((m >> l) & 1ull)) ? ball_idx[st + 64 * (c0 + u) + l] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cl[u] = j[u] >= 0 ? claim[j[u]] : -2;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (c0 + u >= nsl) break;
+                        const unsigned long long wm = __ballot(cl[u] == pos);
+                        if (l == 0) s_wm[q][c0 + u] = wm;
+                        count += __popcll(wm);
+                    }
+                }
+            }
+            if (l == 0) s_cnt[q] = count;
+        }
+        __syncthreads();
+        // ---- tile scan + decoupled look-back over the preceding tiles
+        if (wv == 0) {
+            const int v = l < WIN_TILE ? s_cnt[l] : 0;
+            const int incl = wave_incl_scan(v);
+            if (l < WIN_TILE) s_off[l] = incl - v;
+            const int total = __shfl(incl, 63, 64);
+            // relaxed on purpose: the word carries its own payload, nothing else is ordered by it (an acquire / release
+            // pair at agent scope invalidates / writes back the L2 on every poll: a 10x slower kernel)
+            if (l == 0)
+                __hip_atomic_store(&tile_status[tile], (tile == 0 ? FLAG_INCL : FLAG_AGG) | (unsigned long long)total,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look-back, 64 predecessors per step: sum the aggregates down to the nearest tile whose inclusive prefix
+            // is known (tile -1 counts as "inclusive 0")
+            int base = 0;
+            for (int hi = tile - 1; hi >= 0;) {
+                const int t = hi - l;
+                const unsigned long long sv = t >= 0 ? __hip_atomic_load(&tile_status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                     : FLAG_INCL;
+                const unsigned long long incl_m = __ballot((sv >> 62) == 2ull), inval_m = __ballot((sv >> 62) == 0ull);
+                const int first = incl_m ? __ffsll((long long)incl_m) - 1 : 64;
+                const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                if (inval_m & need) continue;  // a predecessor in the window has not published yet: poll again
+                base += wave_sum(l <= first ? (int)(sv & VAL) : 0);
+                if (first < 64) break;
+                hi -= 64;
+            }
+            if (l == 0) {
+                if (tile > 0)
+                    __hip_atomic_store(&tile_status[tile], FLAG_INCL | (unsigned long long)(base + total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_bcast[1] = base;
+                if (tile == ntiles - 1) counters[6 + ((level + 1) & 1)] = base + total;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: winners out, in (position, slot) order
+        const int base = s_bcast[1];
+        for (int k = 0; k < PER_WAVE; k++) {
+            const int q = wv * PER_WAVE + k, pos = tile * WIN_TILE + q;
+            const int total = s_cnt[q];
+            if (pos >= nF || total == 0) continue;
+            const int node = s_node[q];
+            const int st = s_st[q], ln = s_ln[q];
+            const int nsl = (ln + 63) >> 6;
+            int out = base + s_off[q];
+            if (l == 0) {
                 const int r = root[node];
-                atomicMin(&seg_start[r], base);
-                atomicAdd(&seg_cnt[r], total);
+                atomicMin(&seg_start_next[r], out);
+                atomicAdd(&seg_cnt_next[r], total);
+            }
+            for (int c = 0; c < nsl; c++) {
+                const unsigned long long wm = s_wm[q][c];
+                if (wm == 0ull) continue;
+                if ((wm >> l) & 1ull) {
+                    const int j = ball_idx[st + 64 * c + l];
+                    F_next[out + __popcll(wm & ((1ull << l) - 1ull))] = j;
+                    claim[j] = -1;  // visited
+                }
+                out += __popcll(wm);
             }
         }
+        __syncthreads();
     }
 }
 
@@ -562,7 +706,8 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
 
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
-        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *cnt, *comp_base, *done, *seg_start, *seg_cnt;
+        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2];
+    unsigned long long *amask, *tile_status;
     void *scan_ws;
 };
 size_t carve(BfsWorkspace &w, int N, void *base)
@@ -577,10 +722,14 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.parent = take(nb); w.root = take(nb); w.comp_size = take(nb); w.visited = take(nb); w.claim = take(nb); w.worklist = take(nb);
     w.scratch_node = take(nb); w.scratch_seed = take(nb); w.cl_size = take(nb); w.cl_start = take(nb);
     w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
-    // the chip-wide expansion reuses buffers that are idle until the assembly phase
-    w.Fa = w.keep; w.Fb = w.keep_size; w.cnt = w.cid; w.done = w.out_off;
-    w.comp_base = take(nb); w.seg_start = take(nb); w.seg_cnt = take(nb);
-    w.counters = take(sizeof(int) * 8);
+    // chip-wide expansion: frontier double buffer, per-component bookkeeping double-buffered by level parity, one
+    // 64-bit mask per 64-edge slice of every list (<= 16 slices + 1 per node), scan state per tile of 64 positions
+    w.Fa = take(nb); w.Fb = take(nb);
+    w.comp_base = take(nb);
+    for (int k = 0; k < 2; k++) { w.done[k] = take(nb); w.seg_start[k] = take(nb); w.seg_cnt[k] = take(nb); }
+    w.amask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N * (MAX_SLICES + 1));
+    w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / WIN_TILE + 2));
+    w.counters = take(sizeof(int) * 16);
     w.scan_ws = take(ms3d_scan_workspace_bytes());
     return off;
 }
@@ -605,8 +754,8 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     BfsWorkspace w;
     if (carve(w, N, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
     const int nb = ms3d_divup(N, 256);
-    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
-                                           w.counters);
+    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent, w.comp_size, w.visited, w.claim,
+                                           w.cl_size, w.scratch_seed, w.counters);
     MS3D_LAUNCH_CHECK();
     bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
                                                                          w.parent);
@@ -626,26 +775,21 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         fprintf(stderr, "[bfs] %s N=%d edges=%ld mode=%d hint=%d err=%d\n", tag, N, n_edges, thr.mode, capped_hint, (int)e_); \
     }
     DBG("after select");
+    static const int exp_flags = getenv("MS3D_BFS_EXP") ? atoi(getenv("MS3D_BFS_EXP")) : 0;
     bool replay = true, dense = false;
     const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
     int level = 0;
     auto run_levels = [&](int nlev) -> int {
-        const int grid = 256 * 8;
         for (int it = 0; it < nlev; it++, level++) {
-            int *Fc = (level & 1) ? w.Fb : w.Fa, *Fn = (level & 1) ? w.Fa : w.Fb;
-            int *nFc = w.counters + 6 + (level & 1), *nFn = w.counters + 6 + ((level + 1) & 1);
-            glob_claim_kernel<<<grid, 256, 0, stream>>>(thr, sem, ball_idx, start_len, w.root, Fc, nFc, w.comp_base, w.done,
-                                                       w.seg_start, w.claim, w.scratch_node, w.scratch_seed);
+            const int c = level & 1, n = c ^ 1;
+            int *Fc = c ? w.Fb : w.Fa, *Fn = c ? w.Fa : w.Fb;
+            glob_claim_kernel<<<256 * 8, 256, 0, stream>>>(thr, level, exp_flags, sem, ball_idx, start_len, w.root, Fc, w.counters,
+                                                          w.worklist, w.comp_base, w.done[c], w.done[n], w.seg_start[c],
+                                                          w.seg_start[n], w.seg_cnt[c], w.seg_cnt[n], w.claim,
+                                                          w.scratch_node, w.scratch_seed, w.amask, w.tile_status);
             MS3D_LAUNCH_CHECK();
-            glob_update_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.done, w.seg_start, w.seg_cnt);
-            MS3D_LAUNCH_CHECK();
-            glob_win_kernel<false><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim, w.cnt, nullptr,
-                                                            nullptr, nullptr, nullptr);
-            MS3D_LAUNCH_CHECK();
-            int rc2 = ms3d_exclusive_scan_i32(w.cnt, w.cnt, N, nFn, w.scan_ws, stream);
-            if (rc2) return rc2;
-            glob_win_kernel<true><<<grid, 256, 0, stream>>>(N, ball_idx, start_len, w.root, Fc, nFc, w.claim, nullptr, w.cnt,
-                                                           Fn, w.seg_start, w.seg_cnt);
+            glob_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.claim, w.amask,
+                                                        w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n]);
             MS3D_LAUNCH_CHECK();
         }
         return 0;
@@ -661,13 +805,10 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         if (capped == 0) {
             replay = false;
             dense = true;
-            glob_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done,
-                                                         w.seg_start, w.seg_cnt, w.claim);
+            glob_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done[0],
+                                                         w.seg_start[0], w.seg_cnt[0], w.claim);
             MS3D_LAUNCH_CHECK();
             DBG("after glob_init");
-            int rc2 = run_levels(16);
-            if (rc2) return rc2;
-            DBG("after levels");
         }
     }
     if (replay) {
@@ -681,50 +822,33 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                                                               w.scratch_seed, w.cl_size, w.cl_start);
         MS3D_LAUNCH_CHECK();
     }
-    int host[8];
+    int host[16];
     for (;;) {
         if (dense) {
-            // cnt / Fa / Fb alias the assembly buffers: the (idempotent) assembly below runs after the expansion
+            // 16 levels are launched speculatively (a shifted-coordinate blob is exhausted after ~10) and the frontier
+            // counter is read together with the final counts; a deeper component simply gets 16 more levels -- the
+            // assembly below is idempotent
+            int rc2 = run_levels(16);
+            if (rc2) return rc2;
+            DBG("after levels");
             glob_finish_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.comp_size, w.comp_base, w.cl_size,
                                                            w.cl_start);
             MS3D_LAUNCH_CHECK();
         }
-    bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
-    MS3D_LAUNCH_CHECK();
-    int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
-    if (rc) return rc;
-    rc = ms3d_exclusive_scan_i32(w.keep_size, w.out_off, N, w.counters + 4, w.scan_ws, stream);
-    if (rc) return rc;
-    bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
-                                           w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
-    MS3D_LAUNCH_CHECK();
+        bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
+        MS3D_LAUNCH_CHECK();
+        int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
+        if (rc) return rc;
+        rc = ms3d_exclusive_scan_i32(w.keep_size, w.out_off, N, w.counters + 4, w.scan_ws, stream);
+        if (rc) return rc;
+        bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
+                                               w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
+        MS3D_LAUNCH_CHECK();
         DBG("after emit");
-        MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
         MS3D_CHECK(hipStreamSynchronize(stream));
         if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], level);
         if (!dense || host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
-        // rare: more than `level` BFS levels; the frontier buffers alias the assembly scratch, so the expansion state
-        // cannot be resumed -> finish with the replay kernel from a clean state
-        dense = false;
-        bfs_init_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.comp_size, w.visited, w.claim, w.cl_size, w.scratch_seed,
-                                           w.counters);
-        MS3D_LAUNCH_CHECK();
-        bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
-                                                                         w.parent);
-        MS3D_LAUNCH_CHECK();
-        bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
-        MS3D_LAUNCH_CHECK();
-        bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
-        MS3D_LAUNCH_CHECK();
-        if (n_edges >= (long)N * 24)
-            bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
-                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
-        else
-            bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
-                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
-        MS3D_LAUNCH_CHECK();
     }
     counts[0] = host[3];
     counts[1] = host[4];
