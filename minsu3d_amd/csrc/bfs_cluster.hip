@@ -100,12 +100,53 @@ __global__ void bfs_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
     if (i < 16) counters[i] = 0;
 }
 
-// one wave per point, lanes stride its neighbour list.  The root of i is resolved once per wave; an edge whose
-// neighbour already points at that root is dismissed with one cached load (a stale parent[j] == root(i) is still
-// proof of membership: sets only ever merge), so the label test and the atomic find/union chain run for the few
-// merging edges only.  The kernel is bound by the rate of these random 4-byte reads (170 M edges per step), so when
-// the caller knows the graph is symmetric (no list was cut at the cap) only the j < i half of every list is looked at:
-// the other half is the same undirected edge seen from the other end.
+// Weak components in three steps (the atomics of a union cost ~30x a cached gather on this part -- 5.7 G/s against
+// 240 G/s, tools/gather_micro.hip -- so the edges are looked at with plain loads and unions are kept for the few that
+// need one):
+//   link     : every point unites with two pseudo-randomly picked label-compatible neighbours.  In a dense
+//              neighbourhood graph that alone connects almost every component (a random geometric graph of degree ~4).
+//   compress : parent[i] = root(i) for every point.
+//   verify   : one wave per point, lanes stride its list: an edge whose two ends carry the same (compressed) parent is
+//              dismissed with one cached 4-byte gather; only the rest take the find / union path.  When the caller
+//              knows the graph is symmetric (no list was cut at the cap) only the j < i half of every list is looked at:
+//              the other half is the same undirected edge seen from the other end.
+__global__ void bfs_link_kernel(int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
+                                const int *__restrict__ start_len, int *parent)
+{
+    // parent[] is compressed (every entry a root) when this kernel starts.  Plain, racy stores on purpose: a root is
+    // only ever pointed at a SMALLER index (no cycle can form), a lost race loses one optional link, and the verify
+    // pass (atomic unions) is what guarantees the result -- this pass only has to make its slow path rare.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    if (ln <= 1) return;
+    const unsigned h1 = ((unsigned)i * 0x9E3779B1u) >> 8, h2 = (((unsigned)i ^ 0x5bd1e995u) * 0x85ebca6bu) >> 8;
+    const int j1 = ball_idx[st + (int)(h1 % (unsigned)ln)], j2 = ball_idx[st + (int)(h2 % (unsigned)ln)];
+    const int lab = thr.mode == 0 ? (int)sem[i] : 0;
+    const int ri = parent[i];
+    const int r1 = (thr.mode != 0 || (int)sem[j1] == lab) ? parent[j1] : ri;
+    const int r2 = (thr.mode != 0 || (int)sem[j2] == lab) ? parent[j2] : ri;
+    const int lo = min(ri, min(r1, r2));
+    if (ri != lo) parent[ri] = lo;
+    if (r1 != lo) parent[r1] = lo;
+    if (r2 != lo) parent[r2] = lo;
+}
+
+// parent[i] = root(i).  Plain loads and stores: a stale parent is still an ancestor (pointers only ever move towards
+// the root) and roots do not change while this kernel runs.
+__global__ void bfs_compress_kernel(int N, int *parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int r = parent[i];
+    for (;;) {
+        const int g = parent[r];
+        if (g == r) break;
+        r = g;
+    }
+    parent[i] = r;
+}
+
 __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symmetric, const int16_t *__restrict__ sem,
                                                        const int *__restrict__ ball_idx,
                                                        const int *__restrict__ start_len, int *parent)
@@ -116,12 +157,12 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
         const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
         if (ln <= 1) continue;  // only itself
         const int lab = thr.mode == 0 ? (int)sem[i] : 0;
-        int ri = uf_find(parent, i);
-        // two 64-edge slices per trip: both index loads, then both parent gathers are in flight together
-        for (int t0 = 0; t0 < ln; t0 += 128) {
-            int j[2], pj[2];
+        int ri = parent[i];     // compressed: the root as of the last compress pass (a stale value only costs a find)
+        // four 64-edge slices per trip: the index loads, then the parent gathers are in flight together
+        for (int t0 = 0; t0 < ln; t0 += 256) {
+            int j[4], pj[4];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int t = t0 + 64 * u + l;
                 j[u] = t < ln ? ball_idx[st + t] : INT_BIG;
             }
@@ -129,12 +170,12 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
             // end's business
             if (symmetric && __shfl(j[0], 0, 64) >= i) break;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 const bool look = j[u] != INT_BIG && j[u] != i && (!symmetric || j[u] < i);
                 pj[u] = look ? parent[j[u]] : ri;
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 bool merge = false;
                 if (pj[u] != ri) merge = thr.mode != 0 || (int)sem[j[u]] == lab;  // bfs_cluster.cpp:44
                 if (__ballot(merge) == 0ull) continue;
@@ -142,11 +183,14 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
                 // lane resolves its own neighbour's root, the wave agrees on the smallest root in sight and each distinct
                 // root is hooked under it: the CAS targets are distinct, one round in the common case
                 const int rj = merge ? uf_find(parent, j[u]) : INT_BIG;
-                const int rmin = min(wave_min(rj), ri);
+                const int rme = uf_find(parent, i);
+                const int rmin = min(wave_min(rj), rme);
                 if (merge && rj != rmin) uf_union(parent, rj, rmin);
-                if (ri != rmin && l == 0) uf_union(parent, ri, rmin);
-                const int rnew = uf_find(parent, i);  // refreshed for the next slice
-                if (u == 0 && pj[1] == ri) pj[1] = rnew;  // "already in my set" stays true under the new root
+                if (rme != rmin && l == 0) uf_union(parent, rme, rmin);
+                const int rnew = uf_find(parent, i);  // refreshed for the next slices
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    if (v > u && pj[v] == ri) pj[v] = rnew;  // "already in my set" stays true under the new root
                 ri = rnew;
             }
         }
@@ -425,24 +469,45 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
 // Chip-wide level-synchronous expansion for SYMMETRIC graphs (no list reached the cap): then a weak component is
 // exactly one cluster, seeded by its root, and all qualifying components can be expanded together by every CU.
 // The frontier array F holds, per level, each component's frontier as one contiguous segment in queue order.
-// Two launches per level:
-//   claim : node at frontier position p is assigned its final queue slot and posts atomicMin(claim[j], p) on every
-//           label-compatible neighbour that is not yet visited (visited <=> claim == -1).  This is the ONE pass over
-//           the level's edges that gathers per edge; the edges that posted are remembered as one 64-bit mask per
-//           64-edge slice.  The per-component bookkeeping of the NEXT level (queue base, segment start / size: double
-//           buffered by level parity) and the scan state are reset here as well.
-//   win   : single-pass compaction of the winners (claim[j] == p) in (p, slot) order -- the order in which the serial
-//           FIFO BFS would have pushed them: workgroups take tiles of 64 frontier positions off a ticket counter,
-//           test only the masked edges, scan the tile, chain the tile totals by decoupled look-back, and emit the
-//           winners into F_next (marking them visited).  The first winner of p lowers its component's next segment
-//           start; compaction in p order keeps the segments contiguous.
-// Round 1 ran five kernels and a 3-launch scan per level and gathered claim[j] three times per edge.
+//
+// A node j joins level L+1 under the frontier node with the SMALLEST queue position p among its label-compatible
+// neighbours, and the children of p are appended in ascending index (= the order of p's list): exactly what the
+// serial FIFO loop does.  Posting atomicMin(claim[j], p) per edge -- round 1 -- costs a memory-side atomic per
+// attempt (5.7 G/s on this part against 240 G/s for cached gathers, tools/gather_micro.hip; the L2 of an XCD does not
+// see the other seven's atomics, so most edges towards an unvisited node attempt one).  Three launches per level
+// without hot atomics instead, every per-edge access a plain 8-byte gather of the node word
+//     vp[i] = level:16 | label:16 | frontier position:32        (level 0xFFFF = unvisited):
+//   mark : frontier node p takes its final queue slot and stores cand[j] = L+1 on every unvisited, label-compatible
+//          neighbour (plain store, idempotent).  The symmetric graph turns the question around:
+//   pull : every candidate scans ITS OWN list for the smallest position among the level-L nodes -- that is its parent
+//          p* -- and leaves cc[j] = (L+1, p*), cnt[p*] += 1 (one atomic per discovered node).
+//   win  : single-pass ordered compaction: tiles of frontier positions off a ticket counter, exclusive scan of cnt[]
+//          inside the tile, tile totals chained by decoupled look-back; the positions with children scan their list for
+//          cc[j] == (L+1, p) and write the children to F_next in list order (vp[j] = visited at level L+1).
+// The per-component bookkeeping of the next level (queue base, segment start / size: double-buffered by level parity)
+// is advanced in `mark`.
 // counters: [6] |F| of even levels  [7] |F| of odd levels  [8] tile ticket
-constexpr int WIN_TILE = 16;          // frontier positions per tile
-constexpr int MAX_SLICES = 16;        // 64-edge slices per list (1000-entry cap)
+constexpr int WIN_TILE = 64;          // frontier positions per tile
+constexpr unsigned long long VP_UNVISITED = 0xFFFFull << 48;
+
+__device__ __forceinline__ unsigned long long vp_make(int level, int label, int pos)
+{
+    return ((unsigned long long)(unsigned)(level & 0xFFFF) << 48) | ((unsigned long long)(unsigned)(label & 0xFFFF) << 32) |
+           (unsigned long long)(unsigned)pos;
+}
+
+__global__ void glob_vp_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem, unsigned long long *vp, int *cand,
+                                    unsigned long long *cc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    vp[i] = vp_make(0xFFFF, thr.mode == 0 ? (int)sem[i] : 0, 0);
+    cand[i] = 0;
+    cc[i] = 0ull;  // a claim left behind by an earlier call on this workspace must not match a (level, position) of this one
+}
 
 __global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__restrict__ comp_size, int *counters,
-                                 int *F0, int *comp_base, int *done, int *seg_start, int *seg_cnt, int *claim)
+                                 int *F0, int *comp_base, int *done, int *seg_start, int *seg_cnt, unsigned long long *vp)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int nwork = counters[0];
@@ -454,19 +519,15 @@ __global__ void glob_init_kernel(const int *__restrict__ worklist, const int *__
     done[r] = 0;
     seg_start[r] = w;
     seg_cnt[r] = 1;
-    claim[r] = -1;  // the seed is visited
+    vp[r] = (vp[r] & (0xFFFFull << 32)) | (unsigned long long)(unsigned)w;  // the seed: level 0, position w
 }
 
-// first mask slot of a node's list: strictly increasing with the node, never shared between two nodes
-__device__ __forceinline__ long mask_slot(int st, int node) { return (long)(st >> 6) + node; }
-
-__global__ __launch_bounds__(256) void glob_claim_kernel(
-    Thr thr, int level, int exp_flags, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
-    const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ F, int *counters,
-    const int *__restrict__ worklist, const int *__restrict__ comp_base, const int *__restrict__ done_cur, int *done_next,
-    const int *__restrict__ seg_start_cur, int *seg_start_next, const int *__restrict__ seg_cnt_cur, int *seg_cnt_next,
-    int *claim, int *scratch_node, int *scratch_seed, unsigned long long *__restrict__ amask,
-    unsigned long long *tile_status)
+__global__ __launch_bounds__(256) void glob_mark_kernel(
+    int level, const int *__restrict__ ball_idx, const int *__restrict__ start_len, const int *__restrict__ root,
+    const int *__restrict__ F, int *counters, const int *__restrict__ worklist, const int *__restrict__ comp_base,
+    const int *__restrict__ done_cur, int *done_next, const int *__restrict__ seg_start_cur, int *seg_start_next,
+    const int *__restrict__ seg_cnt_cur, int *seg_cnt_next, const unsigned long long *__restrict__ vp, int *cand, int *cnt,
+    int *scratch_node, int *scratch_seed, unsigned long long *tile_status)
 {
     const int nF = counters[6 + (level & 1)];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -493,39 +554,72 @@ __global__ __launch_bounds__(256) void glob_claim_kernel(
             const int qpos = comp_base[r] + done_cur[r] + (p - seg_start_cur[r]);
             scratch_node[qpos] = node;
             scratch_seed[qpos] = r;
+            cnt[p] = 0;
         }
-        const int st = start_len[node * 2], ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);  // canonical lists: <= 1000
-        const int lab = thr.mode == 0 ? (int)sem[node] : 0;
-        unsigned long long *am = amask + mask_slot(st, node);
-        // four 64-edge slices per trip: the four index loads, then the four claim gathers are in flight together
+        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
+        const unsigned long long want = VP_UNVISITED | (vp[node] & (0xFFFFull << 32));  // unvisited, my label
+        // four 64-edge slices per trip: the four index loads, then the four node-word gathers are in flight together
         for (int t0 = 0; t0 < ln; t0 += 256) {
-            int j[4], c[4];
+            int j[4];
+            unsigned long long v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int t = t0 + 64 * u + l;
                 j[u] = t < ln ? ball_idx[st + t] : -1;
             }
-            int sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = j[u] >= 0 ? vp[j[u]] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if ((v[u] >> 32) == (want >> 32)) cand[j[u]] = level + 1;
+        }
+    }
+}
+
+// one workgroup per 256 nodes: the candidates among them are compacted in LDS, then its waves take them in turn
+__global__ __launch_bounds__(256) void glob_pull_kernel(int N, int level, const int *__restrict__ ball_idx,
+                                                        const int *__restrict__ start_len,
+                                                        const unsigned long long *__restrict__ vp,
+                                                        const int *__restrict__ cand, unsigned long long *__restrict__ cc,
+                                                        int *cnt)
+{
+    __shared__ int s_list[256];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool is_cand = i < N && cand[i] == level + 1;
+    const unsigned long long m = __ballot(is_cand);
+    int base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (is_cand) s_list[base + ballot_rank(m)] = i;
+    __syncthreads();
+    const int n = s_n, l = lane_id();
+    for (int k = wave_id(); k < n; k += 4) {
+        const int node = s_list[k];
+        const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
+        const unsigned long long want = vp_make(level, (int)((vp[node] >> 32) & 0xFFFF), 0) >> 32;  // level L, my label
+        unsigned best = 0xFFFFFFFFu;
+        for (int t0 = 0; t0 < ln; t0 += 256) {
+            int j[4];
+            unsigned long long v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                c[u] = j[u] >= 0 ? claim[j[u]] : -1;
-                // the label gather rides along with the claim gather (one round trip instead of two in a row; the chain
-                // index -> claim -> label -> coherent re-read -> atomic bounds this kernel, not the request rate)
-                sj[u] = (thr.mode == 0 && j[u] >= 0) ? (int)sem[j[u]] : lab;
+                const int t = t0 + 64 * u + l;
+                j[u] = t < ln ? ball_idx[st + t] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (t0 + 64 * u >= ln) break;
-                // stale reads are only ever too large -> a redundant atomic
-                bool post = c[u] > p && sj[u] == lab;
-                // the L2 of an XCD does not see the atomics of the other seven: a cached line keeps saying "unclaimed"
-                // long after the node was taken, and every such edge would post an atomic (memory-side, expensive);
-                // a coherent re-read filters them
-                if (post && !(exp_flags & 2)) post = ld_agent(&claim[j[u]]) > p;
-                if (post && !(exp_flags & 1)) atomicMin(&claim[j[u]], p);
-                const unsigned long long m = __ballot(post);
-                if (l == 0) am[(t0 >> 6) + u] = m;
-            }
+            for (int u = 0; u < 4; u++) v[u] = j[u] >= 0 ? vp[j[u]] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if ((v[u] >> 32) == want) best = min(best, (unsigned)v[u]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, d, 64));
+        if (l == 0 && best != 0xFFFFFFFFu) {
+            cc[node] = ((unsigned long long)(unsigned)(level + 1) << 32) | best;
+            atomicAdd(&cnt[best], 1);
         }
     }
 }
@@ -533,20 +627,18 @@ __global__ __launch_bounds__(256) void glob_claim_kernel(
 __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__restrict__ ball_idx,
                                                        const int *__restrict__ start_len,
                                                        const int *__restrict__ root, const int *__restrict__ F,
-                                                       int *counters, int *claim,
-                                                       const unsigned long long *__restrict__ amask,
+                                                       int *counters, const int *__restrict__ cnt,
+                                                       const unsigned long long *__restrict__ cc, unsigned long long *vp,
                                                        unsigned long long *tile_status, int *F_next, int *seg_start_next,
                                                        int *seg_cnt_next)
 {
-    __shared__ unsigned long long s_wm[WIN_TILE][MAX_SLICES];
     __shared__ int s_cnt[WIN_TILE];
     __shared__ int s_off[WIN_TILE];
-    __shared__ int s_bcast[2];
-    __shared__ int s_node[WIN_TILE], s_st[WIN_TILE], s_ln[WIN_TILE];
+    __shared__ int s_live[WIN_TILE];   // positions of the tile that have children
+    __shared__ int s_bcast[3];
     const int nF = counters[6 + (level & 1)];
     const int ntiles = (nF + WIN_TILE - 1) / WIN_TILE;
     const int l = lane_id(), wv = wave_id();
-    constexpr int PER_WAVE = WIN_TILE / 4;
     constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INCL = 2ull << 62, VAL = (1ull << 62) - 1;
     if ((int)blockIdx.x >= ntiles) return;  // surplus workgroups leave without touching the ticket counter
     for (;;) {
@@ -554,53 +646,15 @@ __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__r
         __syncthreads();
         const int tile = s_bcast[0];
         if (tile >= ntiles) break;
-        if (threadIdx.x < WIN_TILE) {   // the tile's list headers, all positions at once
-            const int pos = tile * WIN_TILE + threadIdx.x;
-            int node = 0, st = 0, ln = 0;
-            if (pos < nF) {
-                node = F[pos];
-                st = start_len[node * 2];
-                ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);
-            }
-            s_node[threadIdx.x] = node; s_st[threadIdx.x] = st; s_ln[threadIdx.x] = ln;
-        }
-        __syncthreads();
-        // ---- pass 1: winners per position, masks kept in LDS
-        for (int k = 0; k < PER_WAVE; k++) {
-            const int q = wv * PER_WAVE + k, pos = tile * WIN_TILE + q;
-            int count = 0;
-            if (pos < nF) {
-                const int node = s_node[q];
-                const int st = s_st[q], ln = s_ln[q];
-                const unsigned long long *am = amask + mask_slot(st, node);
-                const int nsl = (ln + 63) >> 6;
-                const unsigned long long mine = l < nsl ? am[l] : 0ull;   // all slice masks of the list in one load
-                for (int c0 = 0; c0 < nsl; c0 += 4) {   // four slices in flight: index gathers, then claim gathers
-                    int j[4], cl[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const unsigned long long m = __shfl(mine, (c0 + u) & 63, 64);
-                        j[u] = (c0 + u < nsl && ((m >> l) & 1ull)) ? ball_idx[st + 64 * (c0 + u) + l] : -1;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) cl[u] = j[u] >= 0 ? claim[j[u]] : -2;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (c0 + u >= nsl) break;
-                        const unsigned long long wm = __ballot(cl[u] == pos);
-                        if (l == 0) s_wm[q][c0 + u] = wm;
-                        count += __popcll(wm);
-                    }
-                }
-            }
-            if (l == 0) s_cnt[q] = count;
-        }
-        __syncthreads();
-        // ---- tile scan + decoupled look-back over the preceding tiles
+        // ---- tile scan of the child counts + decoupled look-back over the preceding tiles (wave 0)
         if (wv == 0) {
-            const int v = l < WIN_TILE ? s_cnt[l] : 0;
+            const int pos = tile * WIN_TILE + l;
+            const int v = pos < nF ? cnt[pos] : 0;
             const int incl = wave_incl_scan(v);
-            if (l < WIN_TILE) s_off[l] = incl - v;
+            s_cnt[l] = v;
+            s_off[l] = incl - v;
+            const unsigned long long live = __ballot(v > 0);
+            if (v > 0) s_live[ballot_rank(live)] = l;
             const int total = __shfl(incl, 63, 64);
             // relaxed on purpose: the word carries its own payload, nothing else is ordered by it (an acquire / release
             // pair at agent scope invalidates / writes back the L2 on every poll: a 10x slower kernel)
@@ -617,7 +671,10 @@ __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__r
                 const unsigned long long incl_m = __ballot((sv >> 62) == 2ull), inval_m = __ballot((sv >> 62) == 0ull);
                 const int first = incl_m ? __ffsll((long long)incl_m) - 1 : 64;
                 const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
-                if (inval_m & need) continue;  // a predecessor in the window has not published yet: poll again
+                if (inval_m & need) {
+                    __builtin_amdgcn_s_sleep(2);  // a predecessor in the window has not published yet: poll again
+                    continue;
+                }
                 base += wave_sum(l <= first ? (int)(sv & VAL) : 0);
                 if (first < 64) break;
                 hi -= 64;
@@ -627,34 +684,46 @@ __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__r
                     __hip_atomic_store(&tile_status[tile], FLAG_INCL | (unsigned long long)(base + total), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 s_bcast[1] = base;
+                s_bcast[2] = __popcll(live);
                 if (tile == ntiles - 1) counters[6 + ((level + 1) & 1)] = base + total;
             }
         }
         __syncthreads();
-        // ---- pass 2: winners out, in (position, slot) order
-        const int base = s_bcast[1];
-        for (int k = 0; k < PER_WAVE; k++) {
-            const int q = wv * PER_WAVE + k, pos = tile * WIN_TILE + q;
-            const int total = s_cnt[q];
-            if (pos >= nF || total == 0) continue;
-            const int node = s_node[q];
-            const int st = s_st[q], ln = s_ln[q];
-            const int nsl = (ln + 63) >> 6;
+        // ---- children out, in (position, slot) order: the waves take the positions that have children in turn
+        const int base = s_bcast[1], nlive = s_bcast[2];
+        for (int k = wv; k < nlive; k += 4) {
+            const int q = s_live[k], pos = tile * WIN_TILE + q;
+            const int node = F[pos];
+            const int st = start_len[node * 2], ln = start_len[node * 2 + 1];
             int out = base + s_off[q];
             if (l == 0) {
                 const int r = root[node];
                 atomicMin(&seg_start_next[r], out);
-                atomicAdd(&seg_cnt_next[r], total);
+                atomicAdd(&seg_cnt_next[r], s_cnt[q]);
             }
-            for (int c = 0; c < nsl; c++) {
-                const unsigned long long wm = s_wm[q][c];
-                if (wm == 0ull) continue;
-                if ((wm >> l) & 1ull) {
-                    const int j = ball_idx[st + 64 * c + l];
-                    F_next[out + __popcll(wm & ((1ull << l) - 1ull))] = j;
-                    claim[j] = -1;  // visited
+            const unsigned long long mine = ((unsigned long long)(unsigned)(level + 1) << 32) | (unsigned)pos;
+            const unsigned long long lab = vp[node] & (0xFFFFull << 32);
+            for (int t0 = 0; t0 < ln; t0 += 256) {
+                int j[4];
+                unsigned long long c[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u + l;
+                    j[u] = t < ln ? ball_idx[st + t] : -1;
                 }
-                out += __popcll(wm);
+#pragma unroll
+                for (int u = 0; u < 4; u++) c[u] = j[u] >= 0 ? cc[j[u]] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool win = c[u] == mine;
+                    const unsigned long long wm = __ballot(win);
+                    if (win) {
+                        const int o = out + ballot_rank(wm);
+                        F_next[o] = j[u];
+                        vp[j[u]] = ((unsigned long long)(unsigned)((level + 1) & 0xFFFF) << 48) | lab | (unsigned)o;
+                    }
+                    out += __popcll(wm);
+                }
             }
         }
         __syncthreads();
@@ -707,7 +776,8 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
         *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2];
-    unsigned long long *amask, *tile_status;
+    unsigned long long *vp, *cc, *tile_status;
+    int *cand, *cnt;
     void *scan_ws;
 };
 size_t carve(BfsWorkspace &w, int N, void *base)
@@ -723,11 +793,13 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.scratch_node = take(nb); w.scratch_seed = take(nb); w.cl_size = take(nb); w.cl_start = take(nb);
     w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
     // chip-wide expansion: frontier double buffer, per-component bookkeeping double-buffered by level parity, one
-    // 64-bit mask per 64-edge slice of every list (<= 16 slices + 1 per node), scan state per tile of 64 positions
+    // node words / candidate tags / claims / child counts, scan state per tile of 64 positions
     w.Fa = take(nb); w.Fb = take(nb);
     w.comp_base = take(nb);
     for (int k = 0; k < 2; k++) { w.done[k] = take(nb); w.seg_start[k] = take(nb); w.seg_cnt[k] = take(nb); }
-    w.amask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N * (MAX_SLICES + 1));
+    w.vp = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N);
+    w.cc = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N);
+    w.cand = take(nb); w.cnt = take(nb);
     w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / WIN_TILE + 2));
     w.counters = take(sizeof(int) * 16);
     w.scan_ws = take(ms3d_scan_workspace_bytes());
@@ -757,8 +829,16 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     bfs_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent, w.comp_size, w.visited, w.claim,
                                            w.cl_size, w.scratch_seed, w.counters);
     MS3D_LAUNCH_CHECK();
+    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
+    MS3D_LAUNCH_CHECK();
+    bfs_link_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+    MS3D_LAUNCH_CHECK();
+    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
+    MS3D_LAUNCH_CHECK();
     bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
                                                                          w.parent);
+    MS3D_LAUNCH_CHECK();
+    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
     MS3D_LAUNCH_CHECK();
     bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
     MS3D_LAUNCH_CHECK();
@@ -775,7 +855,6 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         fprintf(stderr, "[bfs] %s N=%d edges=%ld mode=%d hint=%d err=%d\n", tag, N, n_edges, thr.mode, capped_hint, (int)e_); \
     }
     DBG("after select");
-    static const int exp_flags = getenv("MS3D_BFS_EXP") ? atoi(getenv("MS3D_BFS_EXP")) : 0;
     bool replay = true, dense = false;
     const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
     int level = 0;
@@ -783,12 +862,14 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         for (int it = 0; it < nlev; it++, level++) {
             const int c = level & 1, n = c ^ 1;
             int *Fc = c ? w.Fb : w.Fa, *Fn = c ? w.Fa : w.Fb;
-            glob_claim_kernel<<<256 * 8, 256, 0, stream>>>(thr, level, exp_flags, sem, ball_idx, start_len, w.root, Fc, w.counters,
-                                                          w.worklist, w.comp_base, w.done[c], w.done[n], w.seg_start[c],
-                                                          w.seg_start[n], w.seg_cnt[c], w.seg_cnt[n], w.claim,
-                                                          w.scratch_node, w.scratch_seed, w.amask, w.tile_status);
+            glob_mark_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.worklist,
+                                                         w.comp_base, w.done[c], w.done[n], w.seg_start[c], w.seg_start[n],
+                                                         w.seg_cnt[c], w.seg_cnt[n], w.vp, w.cand, w.cnt, w.scratch_node,
+                                                         w.scratch_seed, w.tile_status);
             MS3D_LAUNCH_CHECK();
-            glob_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.claim, w.amask,
+            glob_pull_kernel<<<nb, 256, 0, stream>>>(N, level, ball_idx, start_len, w.vp, w.cand, w.cc, w.cnt);
+            MS3D_LAUNCH_CHECK();
+            glob_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.cnt, w.cc, w.vp,
                                                         w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n]);
             MS3D_LAUNCH_CHECK();
         }
@@ -805,8 +886,10 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         if (capped == 0) {
             replay = false;
             dense = true;
+            glob_vp_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, w.vp, w.cand, w.cc);
+            MS3D_LAUNCH_CHECK();
             glob_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done[0],
-                                                         w.seg_start[0], w.seg_cnt[0], w.claim);
+                                                         w.seg_start[0], w.seg_cnt[0], w.vp);
             MS3D_LAUNCH_CHECK();
             DBG("after glob_init");
         }
@@ -828,6 +911,7 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
             // 16 levels are launched speculatively (a shifted-coordinate blob is exhausted after ~10) and the frontier
             // counter is read together with the final counts; a deeper component simply gets 16 more levels -- the
             // assembly below is idempotent
+            if (level > 60000) return MS3D_E_UNSUPPORTED;  // 16-bit level field of the node word
             int rc2 = run_levels(16);
             if (rc2) return rc2;
             DBG("after levels");

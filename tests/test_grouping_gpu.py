@@ -116,6 +116,26 @@ def test_bfs_vs_oracle(be, oracle, kind, n, B, radius, thr):
         assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
 
 
+def test_bfs_workspace_reuse(be, oracle):
+    """different dense graphs of the same size back to back on one workspace: nothing an earlier call left behind
+    (claims, candidate tags, scan state) may leak into the next one"""
+    n = 12000
+    for seed in (1, 2, 3, 1):
+        rng = np.random.default_rng(seed)
+        c = rng.random((6, 3)) * 2
+        xyz = (c[rng.integers(0, 6, n)] + rng.standard_normal((n, 3)) * 0.025).astype(np.float32)
+        b = np.zeros(n, np.uint8); bo = np.array([0, n], np.int32)
+        sem = rng.integers(2, 4, n).astype(np.int16)
+        widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+        assert wsl[:, 1].max() < 1000 and widx.size >= 24 * n      # the chip-wide level-synchronous path
+        idx, sl = be.ballquery_batch_p(dev(xyz), dev(b), dev(bo), 0.03, 300)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        want = oracle.pg_bfs_cluster(sem, widx, wsl, 20)
+        a, o = be.pg_bfs_cluster(dev(sem), idx, sl, 20)
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
 def test_bfs_deterministic(be, oracle):
     rng = np.random.default_rng(9)
     xyz, b, bo = scene(rng, 20000, "surface", 2)
