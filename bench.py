@@ -7,11 +7,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the dominant kernel (the
-3x3x3 16->16 sparse-conv gather kernel at full resolution, forward and backward-data launches); `cpu_baseline`
-times the same training step on the host cores with every operator served by the CPU oracle (a PORT of the
-reference algorithms -- the reference's own CPU path needs MinkowskiEngine, which is not available), on a
-bounded sample, N=1 / rank 0 only.
+Rank 0 prints ONE JSON line.
+
+`roofline`: measured live with HIP events on a sample of the timed steps (every 5th; an event pair costs host time).
+The events are recorded INSIDE the library calls, immediately around each kernel, on the stream it is launched on.
+The object describes the dominant kernel family of the step -- ALL sparse-convolution launches (forward,
+backward-data, backward-weight: the SURVEY 8d / BASELINE.md figure, sum over the layers of
+nM*(Cin+Cout)*4 + nM*8 + K*Cin*Cout*4 with each table's real pair count nM, divided by the summed kernel time) --
+and `top_kernels` lists the five largest kernel groups by time (convolutions by variant and shape, and the grouping
+operators with their SURVEY 8d byte formulas).  `traffic` (HBM bytes from PMC counters) needs separate rocprofv3
+--pmc passes and is therefore not produced by this script: the per-kernel FETCH_SIZE / WRITE_SIZE tables of the
+same command are committed under profiles/ and discussed in DESIGN.md.
+
+`cpu_baseline` times the same training step on the host cores with every operator served by the CPU oracle (a PORT
+of the reference algorithms -- the reference's own CPU path needs MinkowskiEngine, which is not available), on a
+bounded sample (one ~150k-point scene: 1 warm-up + 3 timed steps, median), N=1 / rank 0 only, with a per-operator
+breakdown; `--cpu-config1` runs BASELINE config 1 (4 x ~20k-point scenes) instead.
 """
 import argparse
 import json
@@ -32,7 +43,9 @@ import minsu3d_amd.model as ms_models  # noqa: E402
 import minsu3d_amd.MinkowskiEngine as ME  # noqa: E402
 from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 MFMA (v_mfma_f32_16x16x4_f32), same guide / SURVEY 8d
+SAMPLE_EVERY = 5           # every 5th timed step carries the kernel events
 
 
 def make_batch(seeds, device, scene_kwargs=None, offset_noise=0.04):
@@ -75,28 +88,121 @@ def train_step(model, ddp, opt, batch, next_batch=None):
     return loss
 
 
-def cpu_baseline(cfg, n_points_budget):
-    """the identical step with the CPU oracle behind every operator; bounded sample = ONE ~150k-point scene,
-    one warm-up-free step (tens of seconds on the host cores)"""
+# --------------------------------------------------------------------------------------------- CPU baseline
+_CPU_FAMILIES = (("sparse convolution (forward, backward-data, backward-weight)", ("conv_", "prep_weights")),
+                 ("coordinate maps / quantize", ("sparse_quantize", "kmap", "downsample", "spatial_order", "pairlist",
+                                                 "offsetlist", "identity_table")),
+                 ("batch norm", ("bn_",)),
+                 ("ball query", ("ballquery",)),
+                 ("BFS clustering / aggregation", ("bfs", "hierarchical")),
+                 ("voxelisation segment ops, pools, IoU", ("sec_", "roipool", "global_avg", "get_", "scatter_add")))
+
+
+class _TimedBackend:
+    """proxy that accumulates the wall time of every backend method (the oracle serves them synchronously)"""
+
+    def __init__(self, inner):
+        self._inner, self.seconds = inner, {}
+
+    def __getattr__(self, name):
+        attr = getattr(self._inner, name)
+        if not callable(attr):
+            return attr
+
+        def timed(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return attr(*a, **k)
+            finally:
+                self.seconds[name] = self.seconds.get(name, 0.0) + time.perf_counter() - t0
+        return timed
+
+
+def cpu_baseline(cfg, config1=False):
+    """the identical step with the CPU oracle behind every operator: 1 warm-up + 3 timed steps, median"""
     from oracle.oracle_backend import OracleBackend
-    prev = ms_backend.set_backend(OracleBackend())
+    from oracle import oracle as O
+    proxy = _TimedBackend(OracleBackend())
+    prev = ms_backend.set_backend(proxy)
     try:
         cores = min(os.cpu_count() or 1, 32)   # more threads only thrash on these loop sizes
         torch.set_num_threads(cores)
-        from oracle import oracle as O
         O.lib().orc_set_threads(cores)
         dev = torch.device("cpu")
         model = build(cfg, dev)
         opt = model.configure_optimizers()
-        batch = make_batch([0], dev)
-        t0 = time.perf_counter()
-        train_step(model, model, opt, batch)
-        dt = time.perf_counter() - t0
-        return {"value": round(1.0 / dt, 5), "unit": "scenes/sec", "cores": cores, "kind": "port",
-                "sample": f"1 step on 1 synthetic scene ({batch['point_xyz'].shape[0]} points, "
-                          f"{batch['voxel_xyz'].shape[0]} voxels), {dt:.1f} s, oracle C (OpenMP) + torch CPU"}
+        if config1:   # BASELINE config 1: 4 synthetic ~20k-point scenes (room 2 m x 1.6 m, 3 boxes)
+            batch = make_batch([0, 1, 2, 3], dev, dict(room=(2.0, 1.6), n_boxes=3))
+        else:
+            batch = make_batch([0], dev)
+        n_scenes = len(batch["scan_ids"])
+        times, per_op = [], []
+        for i in range(4):
+            proxy.seconds = {}
+            t0 = time.perf_counter()
+            train_step(model, model, opt, batch)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt); per_op.append(dict(proxy.seconds))
+        mid = int(np.argsort(times)[len(times) // 2])
+        dt, ops = times[mid], per_op[mid]
+        breakdown, used = {}, 0.0
+        for fam, prefixes in _CPU_FAMILIES:
+            t = sum(v for k, v in ops.items() if any(p in k for p in prefixes))
+            breakdown[fam] = round(t, 3); used += t
+        breakdown["dense heads, losses, autograd glue, Adam (torch CPU)"] = round(max(dt - used, 0.0), 3)
+        return {"value": round(n_scenes / dt, 5), "unit": "scenes/sec", "cores": cores, "kind": "port",
+                "sample": f"{n_scenes} synthetic scene(s) ({batch['point_xyz'].shape[0]} points, "
+                          f"{batch['voxel_xyz'].shape[0]} voxels), 1 warm-up + 3 timed steps, median {dt:.2f} s "
+                          f"(all: {', '.join(f'{t:.2f}' for t in times)}), oracle C (OpenMP) + torch CPU",
+                "seconds_per_step_by_operator": breakdown}
     finally:
         ms_backend.set_backend(prev)
+
+
+# --------------------------------------------------------------------------------------------- roofline
+def _conv_variant(kind, K, cin, cout, rows, lib):
+    """the kernel a convolution launch is served by (mirrors fwd_geometry / the wgrad dispatch in csrc/spconv.hip)"""
+    listed = bool(lib.ms3d_kmap_pairlist_wanted(int(K), int(rows)))
+    if kind == "spconv_wgrad":
+        return "offset-list" if listed and cin <= 64 and cout <= 64 else "table-walk"
+    if -(-rows // 16) <= 1100 and -(-cin // 16) * -(-cout // 16) >= 4:
+        return "small"
+    return "pair-list" if listed and max(cin, cout) <= 32 else "table-walk"
+
+
+def roofline_report(groups, n_sampled, lib):
+    """groups: KernelTimer.summary() over `n_sampled` steps -> (roofline dict, top_kernels list)"""
+    if not groups or n_sampled == 0:
+        return None, None
+    conv = {k: v for k, v in groups.items() if k[0].startswith("spconv_")}
+    tot = {f: sum(v[f] for v in conv.values()) for f in ("ms", "bytes", "flops", "launches")}
+    ach = tot["bytes"] / (tot["ms"] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "spconv_* -- every sparse-convolution launch of the step (forward, backward-data, backward-weight; "
+                      "backbone + ScoreNet): sum of algorithmic bytes / sum of kernel time (SURVEY 8d)",
+            "launches_per_step": round(tot["launches"] / n_sampled, 1),
+            "kernel_ms_per_step": round(tot["ms"] / n_sampled, 3),
+            "algorithmic_bytes_per_step": int(tot["bytes"] / n_sampled),
+            "flops_per_step": int(tot["flops"] / n_sampled),
+            "mfma_f32_frac": round(tot["flops"] / (tot["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "steps_sampled": n_sampled}
+    rows = []
+    for k, v in groups.items():
+        if k[0].startswith("spconv_"):
+            _, K, cin, cout, nrows = k
+            kind = "forward/backward-data" if k[0] == "spconv_fwd" else "backward-weight"
+            name = f"{k[0]} [{_conv_variant(k[0], K, cin, cout, nrows, lib)}] {kind} K={K} {cin}->{cout} rows={nrows}"
+        else:
+            name = k[0]
+        gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        rows.append({"name": name, "launches_per_step": round(v["launches"] / n_sampled, 1),
+                     "ms_per_step": round(v["ms"] / n_sampled, 3), "avg_us": round(1e3 * v["ms"] / v["launches"], 1),
+                     "algorithmic_bytes_per_step": int(v["bytes"] / n_sampled), "GB/s": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return roof, rows[:5]
 
 
 def main():
@@ -112,7 +218,9 @@ def main():
                     help="points per m^2 of the synthetic scenes (1700 = the ~150k-point headline workload; small "
                          "values expose the host launch floor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-config1", action="store_true", help="cpu_baseline on BASELINE config 1 (4 x ~20k-point scenes)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--all-kernels", action="store_true", help="print every timed kernel group to stderr")
     args = ap.parse_args()
 
     rank, local, world = init_distributed()
@@ -131,10 +239,8 @@ def main():
     n_vox = float(np.mean([b["voxel_xyz"].shape[0] for b in batches])) / args.batch
 
     timer = None
-    if not args.no_roofline:
-        timer = ms_backend.KernelTimer(lambda name, K, cin, cout: name == "spconv_fwd" and K == 27 and cin == 16 and cout == 16,
-                                       be.lib)
-        timer.min_rows = 50_000 * args.batch      # the backbone's full-resolution level, not the proposal grids of the ScoreNet
+    if not args.no_roofline and rank == 0:
+        timer = ms_backend.KernelTimer(be.lib)
         be.kernel_timer = timer
 
     def sync_all():
@@ -145,11 +251,13 @@ def main():
 
     for i in range(args.warmup):
         train_step(model, ddp, opt, batches[i % args.pool], batches[(i + 1) % args.pool])
-    if timer is not None:
-        timer.enabled = True
     sync_all()
+    n_sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if timer is not None:
+            timer.sampling = i % SAMPLE_EVERY == SAMPLE_EVERY // 2
+            n_sampled += int(timer.sampling)
         loss = train_step(model, ddp, opt, batches[i % args.pool], batches[(i + 1) % args.pool])
     sync_all()
     dt = time.perf_counter() - t0
@@ -175,22 +283,18 @@ def main():
                                            "runs on a side stream during step i's backward; every step builds its own"},
         }
         if timer is not None:
-            s = timer.summary()
-            if s:
-                ach = s["avg_bytes"] / (s["avg_ms"] * 1e-3) / 1e9
-                traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes of this command
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-                if os.path.exists(tpath):
-                    with open(tpath) as f:
-                        traffic = int(json.load(f)["traffic_bytes_per_launch"])
-                line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                    "kernel": "spconv_fwd_pairlist_kernel<1,1> (3x3x3 16->16 pair-list gather/MFMA at full resolution, forward and backward-data launches)",
-                                    "launches": s["launches"], "avg_us": round(s["avg_ms"] * 1e3, 2),
-                                    "algorithmic_bytes_per_launch": int(s["avg_bytes"])}
-        if world == 1 and not args.no_cpu_baseline:
+            timer.sampling = False
             be.kernel_timer = None
-            line["cpu_baseline"] = cpu_baseline(cfg, n_pts)
+            groups = timer.summary()
+            roof, top = roofline_report(groups, n_sampled, be.lib)
+            if roof:
+                line["roofline"], line["top_kernels"] = roof, top
+            if args.all_kernels:
+                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+                    print(f"{v['ms'] / max(n_sampled, 1):8.3f} ms/step {v['launches'] / max(n_sampled, 1):6.1f} launches "
+                          f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, config1=args.cpu_config1)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

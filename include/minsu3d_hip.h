@@ -242,6 +242,7 @@ int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd
  * the convolution kernel only) */
 void *ms3d_event_create(void);
 void ms3d_event_destroy(void *event);
+int ms3d_event_record(void *event, ms3d_stream_t stream);
 float ms3d_event_elapsed_ms(void *start, void *stop);
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
@@ -250,6 +251,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const int *ol_fwd_kt_start /* offset list of nbr_fwd or NULL */, const int *ol_fwd_entries,
                                const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
                                void *ev_start /* hipEvent_t or NULL: around the backward-data kernel */, void *ev_stop,
+                               void *ev_wg_start /* hipEvent_t or NULL: around the backward-weight kernels */, void *ev_wg_stop,
                                ms3d_stream_t stream);
 
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */

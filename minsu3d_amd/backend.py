@@ -119,6 +119,8 @@ class HipBackend:
         ws_bytes = self.lib.ms3d_ballquery_workspace_bytes(n)
         ws = self.ws.get("bq", ws_bytes, dev)
         n_active, capped = C.c_int(0), C.c_int(0)
+        timer = self.kernel_timer
+        ev0 = timer.op_begin() if timer is not None else None
         while True:
             idx = torch.empty(n * meanActive, dtype=torch.int32, device=dev)
             rc = self.lib.ms3d_ballquery_batch_p(
@@ -130,6 +132,9 @@ class HipBackend:
             if n_active.value <= n * meanActive:
                 break
             meanActive = int(n_active.value // n + 1)
+        if ev0 is not None:
+            # n*12 + n*27*c*12 + nActive*4 + n*8; 27*c = candidates per query = hits * 27*1.01^3 / (4/3 pi)
+            timer.op_end("ballquery_batch_p", ev0, n * 20 + n_active.value * (6.64 * 12 + 4))
         # remembered for the clustering call that consumes this graph: "no list reached the 1000 cap" means the graph
         # is symmetric, which lets the BFS skip a device->host check
         start_len._ms3d_capped = int(capped.value)
@@ -147,11 +152,15 @@ class HipBackend:
         ws = self.ws.get("bfs", ws_bytes, dev)
         counts = (C.c_int * 2)(0, 0)
         args_tail = tuple(hint if a is _HINT else a for a in args_tail)
+        timer = self.kernel_timer
+        ev0 = timer.op_begin() if timer is not None else None
         rc = getattr(self.lib, fn_name)(*args_head, _lib.ptr(ball_idx), C.c_long(ball_idx.numel()), _lib.ptr(start_len), N,
                                         *args_tail,
                                         _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), counts, _lib.ptr(ws),
                                         C.c_size_t(ws.numel()), _lib.stream_handle())
         _lib.check(rc, fn_name)
+        if ev0 is not None:   # nActive*4 + n*(2+8+4) + S*8
+            timer.op_end(fn_name[5:], ev0, ball_idx.numel() * 4 + N * 14 + counts[1] * 8)
         return cluster_idxs[:counts[1]], cluster_offsets[:counts[0] + 1]
 
     def pg_bfs_cluster(self, semantic_label, ball_query_idxs, start_len, threshold):
@@ -183,10 +192,14 @@ class HipBackend:
         self.lib.ms3d_hais_workspace_bytes.restype = C.c_size_t
         ws = self.ws.get("hais", self.lib.ms3d_hais_workspace_bytes(N, ncls), dev)
         counts = (C.c_int * 2)(0, 0)
+        timer = self.kernel_timer
+        ev0 = timer.op_begin() if timer is not None else None
         _lib.check(self.lib.ms3d_hierarchical_aggregation(
             _lib.ptr(sem), _lib.ptr(cs), _lib.ptr(batch_idxs), _lib.ptr(ball_idx), C.c_long(ball_idx.numel()),
             _lib.ptr(start_len), N, hint, int(bool(using_set_aggr)), pna, ra, ncls, _lib.ptr(out_idx), _lib.ptr(out_off),
             counts, _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_hierarchical_aggregation")
+        if ev0 is not None:   # the BFS byte model + the centre sums: 12 B per member
+            timer.op_end("hierarchical_aggregation", ev0, ball_idx.numel() * 4 + N * 14 + counts[1] * 8 + N * 12)
         return out_idx[:counts[1]], out_off[:counts[0] + 1]
 
     def hierarchical_aggregation_parts(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
@@ -322,50 +335,71 @@ def _p(t):
 _VP, _I = C.c_void_p, C.c_int
 _FAST_ARGTYPES = {
     "ms3d_spconv_layer_forward": [_VP] * 3 + [_I] * 5 + [_VP] * 2 + [_I] + [_VP] * 5 + [_VP] * 2 + [_VP] * 2 + [_VP],
-    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 2 + [_VP],
+    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 4 + [_VP],
     "ms3d_bn_finalize": [_VP, _I, C.c_long, _I, C.c_float, C.c_float] + [_VP] * 4 + [_VP] * 4 + [_VP],
 }
 
 
 class KernelTimer:
-    """Times selected kernel launches with HIP events recorded INSIDE the library call, immediately before and
-    after the kernel on the stream it is launched on, and keeps the algorithmic byte count of each launch
-    (SURVEY 8d formula with the table's real pair count)."""
+    """Live kernel timing for bench.py's roofline: HIP events recorded on the stream a kernel is launched on --
+    INSIDE the library call, immediately before and after the kernel, for the sparse convolutions (forward,
+    backward-data, backward-weight); around the library call for the grouping operators (they end with the
+    host read of their output size, so the bracket holds exactly their kernels).  Every record carries the
+    ALGORITHMIC byte / flop count of the launch (SURVEY 8d formulas with the launch's real pair / edge counts).
+    Recording is switched on for chosen steps only (`sampling`): an event pair costs a few microseconds of host time."""
 
-    def __init__(self, select, lib, max_records=112):
-        self.min_rows = 0               # only tables with at least this many output rows (full-resolution level)
-        self.max_records = max_records  # sampling: event create/record per launch is host time inside the timed region
-        self.select = select            # (name, K, cin, cout) -> bool
+    def __init__(self, lib):
         self.lib = lib
         lib.ms3d_event_create.restype = C.c_void_p
         lib.ms3d_event_elapsed_ms.restype = C.c_float
-        self.records = []               # (start_event, stop_event, algorithmic_bytes)
-        self._pairs = {}                # table -> number of valid (in, out) pairs
-        self.enabled = False
+        self.records = []               # (group key, start_event, stop_event, bytes or (table, per-pair bytes, const bytes), flops per pair)
+        self.sampling = False
+        self.steps_sampled = 0
 
-    def begin(self, name, K, cin, cout, nbr):
-        if not self.enabled or len(self.records) >= self.max_records or not self.select(name, K, cin, cout) \
-                or nbr.shape[1] < self.min_rows:
+    # ---- convolutions: events are handed to the library, which records them around the kernel
+    def conv(self, kind, K, cin, cout, nbr, rows):
+        """kind: 'fwd' (forward / backward-data, the same kernels) or 'wgrad' -> (ev_start, ev_stop) or None"""
+        if not self.sampling:
             return None
-        nM = getattr(nbr, "_ms3d_pairs", None)      # cached on the table object (an address can be reused by another table)
-        if nM is None:
-            nM = int((nbr >= 0).sum().item())
-            nbr._ms3d_pairs = nM
-        nbytes = nM * (cin + cout) * 4 + nM * 8 + K * cin * cout * 4
-        ev = (C.c_void_p(self.lib.ms3d_event_create()), C.c_void_p(self.lib.ms3d_event_create()), nbytes)
-        self.records.append(ev)
+        pairs = getattr(nbr, "_ms3d_pairs_dev", None)   # valid (in, out) pairs of the table: counted on the device, read
+        if pairs is None:                                # back only in summary() (no host sync inside a step)
+            pairs = (nbr >= 0).sum()
+            nbr._ms3d_pairs_dev = pairs
+        ev = (C.c_void_p(self.lib.ms3d_event_create()), C.c_void_p(self.lib.ms3d_event_create()))
+        self.records.append((("spconv_" + kind, K, cin, cout, rows), ev[0], ev[1],
+                             (pairs, (cin + cout) * 4 + 8, K * cin * cout * 4), 2 * cin * cout))
         return ev
 
-    def summary(self):
-        if not self.records:
+    # ---- grouping operators: bracket a library call on the current stream
+    def op_begin(self):
+        if not self.sampling:
             return None
-        ms = [self.lib.ms3d_event_elapsed_ms(a, b) for a, b, _ in self.records]
-        nb = [n for _, _, n in self.records]
-        for a, b, _ in self.records:
+        ev = C.c_void_p(self.lib.ms3d_event_create())
+        self.lib.ms3d_event_record(ev, _lib.stream_handle())
+        return ev
+
+    def op_end(self, name, ev0, nbytes):
+        ev1 = C.c_void_p(self.lib.ms3d_event_create())
+        self.lib.ms3d_event_record(ev1, _lib.stream_handle())
+        self.records.append(((name,), ev0, ev1, float(nbytes), 0))
+
+    def summary(self):
+        """-> {group key: dict(launches, ms, bytes, flops)} summed over the sampled steps"""
+        out = {}
+        for key, a, b, nb, fpp in self.records:
+            ms = self.lib.ms3d_event_elapsed_ms(a, b)
             self.lib.ms3d_event_destroy(a); self.lib.ms3d_event_destroy(b)
+            if ms < 0:
+                continue
+            flops = 0.0
+            if isinstance(nb, tuple):
+                pairs = float(nb[0].item())
+                flops = pairs * fpp
+                nb = pairs * nb[1] + nb[2]
+            g = out.setdefault(key, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+            g["launches"] += 1; g["ms"] += ms; g["bytes"] += nb; g["flops"] += flops
         self.records = []
-        ms = [m for m in ms if m >= 0]
-        return dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_bytes=sum(nb) / len(nb))
+        return out
 
 
 class _HipEngine:
@@ -638,8 +672,8 @@ class _HipEngine:
             stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev)
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
-        tok = timer.begin("spconv_fwd", K, cin, cout, nbr_fwd) if timer is not None else None
-        ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
+        tok = timer.conv("fwd", K, cin, cout, nbr_fwd, vout) if timer is not None else None
+        ev0, ev1 = tok if tok is not None else (None, None)
         _lib.check(self._fast("ms3d_spconv_layer_forward")(
             _p(x), _p(None if wf_ready is not None else self._dev(W3)), _p(nbr_fwd), int(vout), int(K), int(cin), int(cout),
             int(bool(mirror_bwd)), _p(_f32(ps)), _p(_f32(pb)), int(bool(pre_relu)), _p(_f32(residual)),
@@ -660,15 +694,17 @@ class _HipEngine:
         plf = self.offsetlist(nbr_fwd, K, vout)
         plb = self.pairlist(nbr_bwd, K, vin) if want_dx else (None, None)
         timer = self.kernel_timer
-        tok = timer.begin("spconv_fwd", K, cout, cin, nbr_bwd) if (timer is not None and want_dx) else None
-        ev0, ev1 = (tok[0], tok[1]) if tok is not None else (C.c_void_p(0), C.c_void_p(0))
+        tok = timer.conv("fwd", K, cout, cin, nbr_bwd, vin) if (timer is not None and want_dx) else None
+        ev0, ev1 = tok if tok is not None else (None, None)
+        tok = timer.conv("wgrad", K, cin, cout, nbr_fwd, vout) if timer is not None else None
+        ev2, ev3 = tok if tok is not None else (None, None)
         _lib.check(self._fast("ms3d_spconv_layer_backward")(
             _p(x), _p(dy), _p(wf_buf), _p(nbr_fwd), _p(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _p(bn["scale"] if has_bn else None), _p(bn["shift"] if has_bn else None),
             _p(bn["mean"] if has_bn else None), _p(bn["invstd"] if has_bn else None),
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
             _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
-            _p(plb[1]), ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_backward")
+            _p(plb[1]), ev0, ev1, ev2, ev3, _lib.stream_handle()), "ms3d_spconv_layer_backward")
         return (dx if need_dx else None), dgb, dW
 
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):

@@ -1770,6 +1770,7 @@ void *ms3d_event_create(void)
     return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
 }
 void ms3d_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+int ms3d_event_record(void *e, ms3d_stream_t stream) { return (int)hipEventRecord((hipEvent_t)e, (hipStream_t)stream); }
 // milliseconds between two recorded events (synchronises on `stop`); < 0 on error
 float ms3d_event_elapsed_ms(void *start, void *stop)
 {
@@ -1789,7 +1790,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
                                int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *ol_fwd_kt_start,
                                const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
-                               void *ev_start, void *ev_stop, ms3d_stream_t stream)
+                               void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop, ms3d_stream_t stream)
 {
     const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
     const bool bn = scale != nullptr;
@@ -1826,8 +1827,12 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     }
     const int pb0 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 0), pb1 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 1);
     float *slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
-    return ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs,
-                                       ol_fwd_kt_start, ol_fwd_entries, stream);
+    // second optional event pair: the backward-weight kernel and its slab reduction
+    if (ev_wg_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_start, (hipStream_t)stream));
+    rc = ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs, ol_fwd_kt_start,
+                                     ol_fwd_entries, stream);
+    if (ev_wg_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_stop, (hipStream_t)stream));
+    return rc;
 }
 
 }  // extern "C"
