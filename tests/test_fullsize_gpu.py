@@ -1,0 +1,338 @@
+"""GPU, BASELINE sizes: the operators of configs 2-4 (PointGroup, HAIS, SoftGroup on 4 x ~150k-point synthetic
+ScanNet-shaped scenes) at the size the benchmark runs them.
+
+  * bit-exact oracle comparison on ONE full scene per operator (the CPU oracle needs ~10-20 s per ball query there);
+  * on the full 4-scene batch: size-independent properties checked against independent arithmetic (scipy connected
+    components of the device's own neighbour lists, set algebra of the size thresholds), the batched SoftGroup
+    grouping against the reference's per-class formulation, adjoint identities of the m = 32 convolutions, one
+    HAIS / SoftGroup training step;
+  * the 1e-4 activation bar end to end: the 7-level m = 16 backbone on a full scene against an fp64 restatement,
+    level by level.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RADIUS = 0.03
+
+
+@pytest.fixture(scope="module")
+def be():
+    from minsu3d_amd.backend import HipBackend
+    return HipBackend()
+
+
+def _inputs(seeds, offset_noise=0.04):
+    """foreground points of the benchmark's scenes: original / shifted coordinates, labels, scene ids (numpy)"""
+    import bench
+    b = bench.make_batch(list(seeds), torch.device("cpu"), offset_noise=offset_noise)
+    sem = b["grouping_semantic_preds"].numpy()
+    fg = sem >= 2
+    obj = np.nonzero(fg)[0]
+    bi = b["vert_batch_ids"].numpy()[obj]
+    bo = np.concatenate([[0], np.cumsum(np.bincount(bi, minlength=len(seeds)))]).astype(np.int32)
+    xyz = b["point_xyz"].numpy()[obj]
+    sh = (xyz + b["grouping_point_offsets"].numpy()[obj]).astype(np.float32)
+    return dict(xyz=np.ascontiguousarray(xyz), shifted=np.ascontiguousarray(sh), sem=np.ascontiguousarray(sem[obj]),
+                batch_idxs=np.ascontiguousarray(bi), batch_offsets=bo, batch=b, object_idxs=obj)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# HAIS statistics of the synthetic classes: chosen so that the three size classes (dropped / kept fragment / primary) and
+# the set aggregation all occur on the synthetic scenes (instances of 2 000 - 13 000 points, which the 4 cm offset noise
+# surrounds with stray components of a few points)
+POINT_NUM_AVG = [-1.0, -1.0] + [40.0, 20.0] * 9
+RADIUS_AVG = [-1.0, -1.0] + [0.6, 0.3] * 9
+
+
+@pytest.mark.parametrize("using_set_aggr", [False, True])
+def test_hais_grouping_one_full_scene_vs_oracle(be, oracle, using_set_aggr):
+    """model/hais.py:45-56 on one ~150k-point scene: bit-exact against the CPU restatement of
+    hierarchical_aggregation.cpp:8-184 / .cu:20-204 / hais_ops.py:55-73"""
+    d = _inputs([0])
+    widx, wsl = oracle.ballquery_batch_p(d["shifted"], d["batch_idxs"], d["batch_offsets"], RADIUS)
+    idx, sl = be.ballquery_batch_p(dev(d["shifted"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), RADIUS, 300)
+    assert np.array_equal(sl.cpu().numpy(), wsl) and np.array_equal(idx.cpu().numpy(), widx)
+    assert widx.size > 100 * len(d["sem"])                                        # the dense regime HAIS groups in
+    want = oracle.hierarchical_aggregation(d["sem"], d["shifted"], widx, wsl, d["batch_idxs"], using_set_aggr,
+                                           POINT_NUM_AVG, RADIUS_AVG)
+    a, o = be.hierarchical_aggregation(dev(d["sem"]), dev(d["shifted"]), idx, sl, dev(d["batch_idxs"]), using_set_aggr,
+                                       POINT_NUM_AVG, RADIUS_AVG, -1)
+    assert len(want[1]) > 5
+    assert np.array_equal(o.cpu().numpy(), want[1])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+def _components(idx, sl, sem):
+    """label-filtered connected components of the neighbour lists with scipy (independent of the oracle)"""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as cg
+    n = sl.shape[0]
+    rows = np.repeat(np.arange(n), sl[:, 1])
+    m = sem[rows] == sem[idx]
+    A = sp.csr_matrix((np.ones(int(m.sum()), np.int8), (rows[m], idx[m])), shape=(n, n))
+    return cg.connected_components(A, directed=False)
+
+
+def test_hais_grouping_full_batch_properties(be):
+    """4 scenes (~230k foreground points, ~45 M edges): the clusters of hierarchical_aggregation against scipy's
+    connected components of the device's own graph and the size thresholds of hierarchical_aggregation.cpp:58-75"""
+    d = _inputs([0, 1, 2, 3])
+    n = len(d["sem"])
+    idx, sl = be.ballquery_batch_p(dev(d["shifted"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), RADIUS, 300)
+    idx_c, sl_c = idx.cpu().numpy(), sl.cpu().numpy()
+    ncomp, lab = _components(idx_c, sl_c, d["sem"])
+    size = np.bincount(lab, minlength=ncomp)
+    seed = np.full(ncomp, n, np.int64)
+    np.minimum.at(seed, lab, np.arange(n))
+    mean = np.asarray(POINT_NUM_AVG, np.float32)[d["sem"][seed]]
+    low, high = (0.05 * mean.astype(np.float64)).astype(np.float32), (0.3 * mean.astype(np.float64)).astype(np.float32)
+    kept = (size.astype(np.float32) >= low) & (size.astype(np.float32) < high)
+    prim = size.astype(np.float32) >= high
+    assert kept.sum() > 0 and prim.sum() > 10
+    a, o = be.hierarchical_aggregation(dev(d["sem"]), dev(d["shifted"]), idx, sl, dev(d["batch_idxs"]), False,
+                                       POINT_NUM_AVG, RADIUS_AVG, -1)
+    a, o = a.cpu().numpy().reshape(-1, 2), o.cpu().numpy()
+    assert len(o) - 1 == kept.sum() + prim.sum() and o[0] == 0 and o[-1] == len(a)
+    assert np.array_equal(a[:, 0], np.repeat(np.arange(len(o) - 1), np.diff(o)))          # cluster ids follow offsets
+    first = a[o[:-1], 1]                                                                     # BFS order starts at the seed
+    comp_of_cluster = lab[first]
+    assert np.array_equal(first, seed[comp_of_cluster])
+    assert np.array_equal(np.diff(o), size[comp_of_cluster])                                 # whole components
+    assert np.array_equal(lab[a[:, 1]], np.repeat(comp_of_cluster, np.diff(o)))              # and nothing else
+    nk = int(kept.sum())                                                                     # kept fragments first, both
+    assert kept[comp_of_cluster[:nk]].all() and prim[comp_of_cluster[nk:]].all()             # groups by ascending seed
+    assert (np.diff(first[:nk]) > 0).all() and (np.diff(first[nk:]) > 0).all()
+    # set aggregation only ever appends whole fragments to primaries
+    a2, o2 = be.hierarchical_aggregation(dev(d["sem"]), dev(d["shifted"]), idx, sl, dev(d["batch_idxs"]), True,
+                                         POINT_NUM_AVG, RADIUS_AVG, -1)
+    a2, o2 = a2.cpu().numpy().reshape(-1, 2), o2.cpu().numpy()
+    assert len(o2) == len(o) and np.array_equal(o2[:nk + 1], o[:nk + 1]) and (np.diff(o2)[nk:] >= np.diff(o)[nk:]).all()
+    absorbed = 0
+    for c in range(nk, len(o) - 1):
+        own = np.diff(o)[c]
+        assert np.array_equal(a2[o2[c]:o2[c] + own, 1], a[o[c]:o[c] + own, 1])
+        extra = a2[o2[c] + own:o2[c + 1], 1]
+        if len(extra):
+            absorbed += len(extra)
+            fr = np.unique(lab[extra])
+            assert (~prim[fr]).all() and (d["sem"][extra] == d["sem"][a[o[c], 1]]).all()   # fragments of the same class
+            assert (d["batch_idxs"][extra] == d["batch_idxs"][a[o[c], 1]]).all()           # and scene
+    assert absorbed > 0
+
+
+def _softgroup_model():
+    from test_model_cpu import _build
+    m = _build("softgroup", seed=4).cuda()
+    m.hparams.cfg.data.point_num_avg = [-1, -1] + [3000.0] * 18
+    return m
+
+
+def test_softgroup_batched_grouping_full_batch_equals_per_class_loop():
+    """model/softgroup.py:43-83 on the 4-scene benchmark batch: one ball query + one BFS over all (class, point) rows
+    must equal the reference's formulation, a ball query + sg_bfs_cluster per class"""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    import bench
+    backend.set_backend(HipBackend())
+    m = _softgroup_model()
+    b = bench.make_batch([0, 1, 2, 3], torch.device("cuda", 0))
+    sem = b["grouping_semantic_scores"].clone()
+    lab = b["grouping_semantic_preds"].long()
+    n = sem.size(0)
+    sem[torch.arange(n, device="cuda"), (lab + 3) % 20] = 0.3          # a second class above the score threshold
+    a1, o1 = m._soft_grouping_loop(b, sem, b["grouping_point_offsets"])
+    a2, o2 = m._soft_grouping(b, sem, b["grouping_point_offsets"])
+    assert o1.numel() > 40 and torch.equal(o1, o2) and torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("noise", [0.04, 0.012])
+def test_sg_bfs_cluster_one_full_scene_vs_oracle(be, oracle, noise):
+    """sg_bfs_cluster (bfs_cluster.cpp:102-139,168-187) on one full scene; the small offset noise collapses the
+    instances until lists hit the 1000-neighbour cap: the DIRECTED case (hard part 1)"""
+    d = _inputs([1], offset_noise=noise)
+    widx, wsl = oracle.ballquery_batch_p(d["shifted"], d["batch_idxs"], d["batch_offsets"], RADIUS)
+    idx, sl = be.ballquery_batch_p(dev(d["shifted"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), RADIUS, 300)
+    assert np.array_equal(sl.cpu().numpy(), wsl) and np.array_equal(idx.cpu().numpy(), widx)
+    assert (wsl[:, 1].max() == 1000) == (noise < 0.02)
+    mean = [-1.0, 300.0, 5000.0]
+    for class_id in range(3):
+        want = oracle.sg_bfs_cluster(mean, widx, wsl, 0.1, class_id)
+        a, o = be.sg_bfs_cluster(mean, idx, sl, 0.1, class_id)
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    sem = d["sem"]
+    want = oracle.pg_bfs_cluster(sem, widx, wsl, 50)
+    a, o = be.pg_bfs_cluster(dev(sem), idx, sl, 50)
+    assert np.array_equal(o.cpu().numpy(), want[1]) and np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+@pytest.mark.parametrize("cin,cout,level", [(32, 32, 0), (64, 64, 1), (96, 96, 2), (64, 32, 0)])
+def test_m32_adjoint_identities_at_bench_size(be, cin, cout, level):
+    """the m = 32 widths of HAIS / SoftGroup on the benchmark's own tables: <conv_W(x), g> = <x, conv_W^T(g)> =
+    <W, dW(x, g)> and linearity (no oracle needed at this size)"""
+    from minsu3d_amd.data import synthetic
+    from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
+    b = synthetic.to_torch(synthetic.collate([synthetic.make_scene(s) for s in range(4)]), torch.device("cuda", 0))
+    cm = CoordinateManager(b["voxel_xyz"].int().contiguous(), spatial_sort=True)
+    ts = 1
+    for _ in range(level):
+        cm.k2(ts); ts *= 2
+    nbr, V, K = cm.k3(ts), cm.size(ts), 27
+    g = torch.Generator(device="cuda").manual_seed(level + cin)
+    x = torch.randn(V, cin, device="cuda", generator=g); x2 = torch.randn(V, cin, device="cuda", generator=g)
+    gy = torch.randn(V, cout, device="cuda", generator=g)
+    W = torch.randn(K, cin, cout, device="cuda", generator=g) / (cin * K) ** 0.5
+    wf, wft = be.prep_weights_pair(W, K, cin, cout, mirror_bwd=True)
+    y = be.conv_forward(x, wf, nbr, V, K, cin, cout)
+    dx = be.conv_forward(gy, wft, nbr, V, K, cout, cin)
+    dW = be.conv_backward_weight(x, gy, nbr, V, K, cin, cout)
+    a = torch.dot(y.double().flatten(), gy.double().flatten())
+    # the three inner products are sums of ~1e7 terms of either sign that largely cancel: the yardstick is the size of
+    # the terms (their 2-norm), not the accidental size of the sum
+    scale = (y.double() * gy.double()).norm()
+    assert abs(a - torch.dot(x.double().flatten(), dx.double().flatten())) < 1e-5 * scale
+    assert abs(a - torch.dot(W.double().flatten(), dW.double().flatten())) < 1e-5 * scale
+    y12 = be.conv_forward(x + 2 * x2, wf, nbr, V, K, cin, cout)
+    want = y + 2 * be.conv_forward(x2, wf, nbr, V, K, cin, cout)
+    assert ((y12 - want).abs().max() / want.abs().max()).item() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["hais", "softgroup"])
+def test_training_step_at_bench_size(name):
+    """configs 3 / 4: one full training step (m = 32, 4 scenes, grouping + refinement branch on) on the HIP path"""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from minsu3d_amd.config import load_config
+    import bench
+    backend.set_backend(HipBackend())
+    cfg = load_config([f"model={name}", "data=scannetv2"])
+    assert cfg.model.network.m == 32
+    model = bench.build(cfg, torch.device("cuda", 0))
+    opt = model.configure_optimizers()
+    batch = bench.make_batch([0, 1, 2, 3], torch.device("cuda", 0))
+    out = model(batch)
+    losses = model._loss(batch, out)
+    total = sum(losses.values())
+    assert torch.isfinite(total).item() and len(losses) >= 4
+    off = out["proposal_scores"][2] if name == "hais" else out["proposals_offset"]
+    assert off.numel() - 1 >= 30                                   # the grouping found the synthetic instances
+    total.backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 150 and all(torch.isfinite(g).all().item() for g in grads)
+    opt.step()
+
+
+# --------------------------------------------------------------------------- the 1e-4 activation bar, end to end
+def _ref_conv(x, W, nbr):
+    xp = torch.cat([x, x.new_zeros(1, x.size(1))], 0)
+    out = x.new_zeros(nbr.size(1), W.size(2))
+    for k in range(nbr.size(0)):
+        idx = nbr[k].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, x.size(0)), idx)
+        out += xp[idx] @ W[k]
+    return out
+
+
+def _ref_bn_relu(x, mbn):
+    bn = mbn.bn
+    return torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight.double(), bn.bias.double(), True, 0.1, bn.eps))
+
+
+def _ref_block(h, blk, nbr):
+    skip = h if blk.downsample is None else h @ blk.downsample[0].kernel.double()
+    cb = blk.conv_branch
+    a = _ref_conv(_ref_bn_relu(h, cb[0]), cb[2].kernel.double(), nbr)
+    a = _ref_conv(_ref_bn_relu(a, cb[3]), cb[5].kernel.double(), nbr)
+    return a + skip
+
+
+def _ref_ublock(h, ub, cm, ts, acts):
+    nbr = cm.k3(ts)
+    for blk in ub.blocks:
+        h = _ref_block(h, blk, nbr)
+    acts.append(h)
+    if len(ub.nPlanes) == 1:
+        return h
+    down, up = cm.k2(ts)
+    d = _ref_conv(_ref_bn_relu(h, ub.conv[0]), ub.conv[2].kernel.double(), down)
+    d = _ref_ublock(d, ub.u, cm, 2 * ts, acts)
+    u = _ref_conv(_ref_bn_relu(d, ub.deconv[0]), ub.deconv[2].kernel.double(), up)
+    h = torch.cat([h, u], 1)
+    for blk in ub.blocks_tail:
+        h = _ref_block(h, blk, nbr)
+    acts.append(h)
+    return h
+
+
+def test_backbone_activations_within_1e4_of_fp64_on_a_full_scene():
+    """north_star: <= 1e-4 relative error on sparse-conv activations.  The whole 7-level m = 16 U-Net (53 3x3x3
+    convolutions, 12 strided / transposed ones, 65 batch norms, fused as the engine fuses them) on one ~106k-voxel
+    benchmark scene against a plain fp64 gather-matmul restatement over the same kernel maps: every encoder and
+    decoder level's activations, and the network output."""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from minsu3d_amd.config import load_config
+    from minsu3d_amd.data import synthetic
+    from minsu3d_amd.model.module.common import UBlock
+    import minsu3d_amd.MinkowskiEngine as ME
+    import bench
+    backend.set_backend(HipBackend())
+    cfg = load_config(["model=pointgroup", "data=scannetv2"])
+    model = bench.build(cfg, torch.device("cuda", 0), seed=7)
+    unet = model.backbone.unet
+    b = synthetic.to_torch(synthetic.collate([synthetic.make_scene(5)]), torch.device("cuda", 0))
+    x = ME.SparseTensor(features=b["voxel_features"], coordinates=b["voxel_xyz"])
+    cm = x.coordinate_manager
+    cm.prepare(model.backbone.n_levels)
+    got = []
+    hooks = []
+    for mod in unet.modules():
+        if isinstance(mod, UBlock):
+            hooks.append(mod.blocks.register_forward_hook(lambda m_, i_, o_: got.append(("enc", o_._raw().detach().clone()))))
+            if len(mod.nPlanes) > 1:
+                hooks.append(mod.blocks_tail.register_forward_hook(lambda m_, i_, o_: got.append(("dec", o_._raw().detach().clone()))))
+    with torch.no_grad():
+        ME.prepare_conv_weights(model)
+        y = unet(x)._raw()
+        ME.release_conv_weights()
+    for h in hooks:
+        h.remove()
+    # fp64 restatement, same traversal order as the module tree (encoder levels going down, decoder levels coming up)
+    acts = []
+    with torch.no_grad():
+        h = _ref_conv(x._raw().double(), unet[0].kernel.double(), cm.k3(1))
+        h = _ref_ublock(h, unet[1], cm, 1, acts)
+        want = _ref_bn_relu(h, unet[2])
+    assert len(acts) == len(got) == 2 * model.backbone.n_levels - 1
+    worst = 0.0
+    for (kind, g), w in zip(got, acts):
+        assert g.shape == w.shape
+        err = ((g.double() - w).abs().max() / w.abs().max()).item()
+        worst = max(worst, err)
+        assert err <= 1e-4, (kind, tuple(g.shape), err)
+    err = ((y.double() - want).abs().max() / want.abs().max()).item()
+    assert err <= 1e-4, err
+    print(f"backbone activations vs fp64: worst level {worst:.2e}, output {err:.2e}")
+
+
+def test_scatter_add_rows_vs_index_add(be):
+    """ms3d_scatter_add_rows (backward of features[v2p_map], backbone.py:40; general_model.py:156; pointgroup.py:88):
+    float atomics, compared with torch.index_add_ in fp64 at the benchmark's sizes, plus the degenerate index patterns"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n_src, n_dst, C_ in ((573000, 417000, 16), (231000, 573000, 32), (5000, 7, 19), (64, 64, 1)):
+        src = torch.randn(n_src, C_, device="cuda", generator=g)
+        idx = torch.randint(0, n_dst, (n_src,), device="cuda", generator=g)
+        if n_dst == 7:
+            idx[:4000] = 3                                                    # one hot destination row
+        got = be.scatter_add_rows(src, idx, n_dst)
+        want = torch.zeros(n_dst, C_, device="cuda", dtype=torch.float64).index_add_(0, idx, src.double())
+        scale = want.abs().max().item()
+        assert got.shape == (n_dst, C_) and (got.double() - want).abs().max().item() <= 2e-6 * max(scale, 1.0) * max(1, n_src // n_dst) ** 0.5
+    out = be.scatter_add_rows(torch.zeros(0, 16, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 5)
+    assert out.shape == (5, 16) and not out.any()
