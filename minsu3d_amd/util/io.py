@@ -38,7 +38,7 @@ def save_prediction(save_path, all_pred_insts, mapping_ids, ignored_classes_indi
 
 
 def read_gt_files_from_disk(data_path):
-    scene = torch.load(data_path)
+    scene = torch.load(data_path, weights_only=False)      # pickled numpy arrays (data/scannetv2/preprocess_all_data.py)
     centred = scene["xyz"] - scene["xyz"].mean(axis=0)
     scene["xyz"] = centred
     return centred, scene["sem_labels"], scene["instance_ids"]
