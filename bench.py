@@ -9,7 +9,7 @@
 
 Rank 0 prints ONE JSON line.
 
-`roofline`: measured live with HIP events on a sample of the timed steps (every 5th; an event pair costs host time).
+`roofline`: measured live with HIP events on a sample of the timed steps (every 10th; an event pair costs host time).
 The events are recorded INSIDE the library calls, immediately around each kernel, on the stream it is launched on.
 The object describes the dominant kernel family of the step -- ALL sparse-convolution launches (forward,
 backward-data, backward-weight: the SURVEY 8d / BASELINE.md figure, sum over the layers of
@@ -45,7 +45,7 @@ from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp  
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 MFMA (v_mfma_f32_16x16x4_f32), same guide / SURVEY 8d
-SAMPLE_EVERY = 5           # every 5th timed step carries the kernel events
+SAMPLE_EVERY = 10          # every 10th timed step carries the kernel events
 
 
 def make_batch(seeds, device, scene_kwargs=None, offset_noise=0.04):
@@ -241,6 +241,7 @@ def main():
     timer = None
     if not args.no_roofline and rank == 0:
         timer = ms_backend.KernelTimer(be.lib)
+        timer.reserve(700 * (args.steps // SAMPLE_EVERY + 1))
         be.kernel_timer = timer
 
     def sync_all():

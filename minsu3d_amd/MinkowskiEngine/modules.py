@@ -124,6 +124,8 @@ class MinkowskiBatchNorm(nn.Module):
         # count is kept on the host and added to the buffer whenever somebody reads it (state_dict / checkpoint)
         self._pending_batches = 0
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_batches_tracked())
+        # a loaded num_batches_tracked replaces the count, it is not added to what this instance had pending
+        self.register_load_state_dict_pre_hook(lambda module, *a, **k: setattr(module, "_pending_batches", 0))
 
     def flush_batches_tracked(self):
         if self._pending_batches and self.bn.num_batches_tracked is not None:
@@ -138,7 +140,11 @@ class MinkowskiBatchNorm(nn.Module):
             with torch.no_grad():
                 rm = bn.running_mean if (self.training and bn.track_running_stats) else None
                 rv = bn.running_var if rm is not None else None
-                mom = 0.1 if bn.momentum is None else bn.momentum
+                if bn.momentum is None:     # cumulative moving average: 1 / (batches seen so far, this one included)
+                    seen = self._pending_batches + (int(bn.num_batches_tracked) if rm is not None else 0)
+                    mom = 1.0 / (seen + 1)
+                else:
+                    mom = bn.momentum
                 g = bn.weight.detach() if bn.affine else None
                 b = bn.bias.detach() if bn.affine else None
                 if x._stats is not None and x._stats.numel() > 0 and x._pending is None:

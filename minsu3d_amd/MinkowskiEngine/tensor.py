@@ -118,7 +118,9 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True):
 
     _PREFETCHED[key] = (worker().submit(build), coordinates)
     while len(_PREFETCHED) > 2:      # prefetched but never used (end of an epoch, a skipped batch): do not pile up
-        _PREFETCHED.pop(next(iter(_PREFETCHED)))
+        fut, coords = _PREFETCHED.pop(next(iter(_PREFETCHED)))
+        # its kernels may still be reading `coords` on the side stream when the last reference goes away here
+        fut.add_done_callback(lambda f, c=coords, s=side: c.record_stream(s))
 
 
 def _take_prefetched(coordinates):
@@ -130,6 +132,9 @@ def _take_prefetched(coordinates):
     cur.wait_event(ev)
     # everything was allocated under the side stream and is used (and eventually freed) under this one
     held = [cm.perm, cm.inv] + list(cm.coords.values()) + list(cm._k3.values()) + [t for pair in cm._k2.values() for t in pair]
+    ext = getattr(cm, "coords_external", None)
+    if ext is not None and ext is not coordinates:
+        held.append(ext)     # an int32 copy made on the side stream (the caller's coordinates had another dtype)
     for t in list(held):
         if t is not None:
             for attr in ("_ms3d_pairlist", "_ms3d_offsetlist"):

@@ -355,6 +355,14 @@ class KernelTimer:
         self.records = []               # (group key, start_event, stop_event, bytes or (table, per-pair bytes, const bytes), flops per pair)
         self.sampling = False
         self.steps_sampled = 0
+        self._pool = []                 # events are created up front: hipEventCreate inside a timed step is host time
+
+    def reserve(self, n_events):
+        while len(self._pool) < n_events:
+            self._pool.append(C.c_void_p(self.lib.ms3d_event_create()))
+
+    def _event(self):
+        return self._pool.pop() if self._pool else C.c_void_p(self.lib.ms3d_event_create())
 
     # ---- convolutions: events are handed to the library, which records them around the kernel
     def conv(self, kind, K, cin, cout, nbr, rows):
@@ -365,7 +373,7 @@ class KernelTimer:
         if pairs is None:                                # back only in summary() (no host sync inside a step)
             pairs = (nbr >= 0).sum()
             nbr._ms3d_pairs_dev = pairs
-        ev = (C.c_void_p(self.lib.ms3d_event_create()), C.c_void_p(self.lib.ms3d_event_create()))
+        ev = (self._event(), self._event())
         self.records.append((("spconv_" + kind, K, cin, cout, rows), ev[0], ev[1],
                              (pairs, (cin + cout) * 4 + 8, K * cin * cout * 4), 2 * cin * cout))
         return ev
@@ -374,12 +382,12 @@ class KernelTimer:
     def op_begin(self):
         if not self.sampling:
             return None
-        ev = C.c_void_p(self.lib.ms3d_event_create())
+        ev = self._event()
         self.lib.ms3d_event_record(ev, _lib.stream_handle())
         return ev
 
     def op_end(self, name, ev0, nbytes):
-        ev1 = C.c_void_p(self.lib.ms3d_event_create())
+        ev1 = self._event()
         self.lib.ms3d_event_record(ev1, _lib.stream_handle())
         self.records.append(((name,), ev0, ev1, float(nbytes), 0))
 

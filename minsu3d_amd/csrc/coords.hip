@@ -31,23 +31,27 @@ __device__ __forceinline__ unsigned long long pack_key(int b, int x, int y, int 
 }
 __device__ __forceinline__ int floor_div(int v, int d) { return (v >= 0) ? (v / d) : -((-v + d - 1) / d); }
 
-__global__ void table_clear_kernel(unsigned long long *keys, int *vals, int H)
+__global__ void table_clear_kernel(unsigned long long *keys, int *vals, int H, int *range_flag)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < H) {
         keys[t] = EMPTY_KEY;
         vals[t] = 0x7fffffff;
     }
+    if (t == 0) *range_flag = 0;
 }
 
 // insert (optionally the stride-`q` floored coordinate) with value = min row; slot_of_row remembers the slot
+// A coordinate outside [-16384, 16384) or a batch / cluster id outside [0, 524288) does not fit the key and would alias
+// another voxel: range_flag is raised and the entry points that read a count back return MS3D_E_UNSUPPORTED.
 __global__ void table_insert_kernel(const int *__restrict__ coords, int n, int q, unsigned long long *keys, int *vals,
-                                    unsigned mask, int *__restrict__ slot_of_row)
+                                    unsigned mask, int *__restrict__ slot_of_row, int *range_flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int4 c = reinterpret_cast<const int4 *>(coords)[i];
     int x = c.y, y = c.z, z = c.w;
+    if (!(in_range(x) && in_range(y) && in_range(z) && c.x >= 0 && c.x <= 0x7FFFF) && *range_flag == 0) atomicOr(range_flag, 1);
     if (q > 1) {
         x = floor_div(x, q) * q;
         y = floor_div(y, q) * q;
@@ -198,10 +202,10 @@ size_t carve(CoordWs &w, int n, void *base)
 
 int build_table(CoordWs &w, const int *coords, int n, int q, hipStream_t stream)
 {
-    table_clear_kernel<<<ms3d_divup(w.H, 256), 256, 0, stream>>>(w.keys, w.vals, w.H);
+    table_clear_kernel<<<ms3d_divup(w.H, 256), 256, 0, stream>>>(w.keys, w.vals, w.H, w.total + 1);
     MS3D_LAUNCH_CHECK();
     table_insert_kernel<<<ms3d_divup(n, 256), 256, 0, stream>>>(coords, n, q, w.keys, w.vals, (unsigned)w.H - 1u,
-                                                              w.slot_of_row);
+                                                              w.slot_of_row, w.total + 1);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -212,8 +216,11 @@ int rank_first(CoordWs &w, int n, int *count_host, hipStream_t stream)
     int rc = ms3d_exclusive_scan_i32(w.flag, w.rank, n, w.total, w.scan_ws, stream);
     if (rc) return rc;
     if (count_host) {
-        MS3D_CHECK(hipMemcpyAsync(count_host, w.total, sizeof(int), hipMemcpyDeviceToHost, stream));
+        int h[2] = {0, 0};   // [0] number of distinct coordinates  [1] a coordinate did not fit the key (table_insert_kernel)
+        MS3D_CHECK(hipMemcpyAsync(h, w.total, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
         MS3D_CHECK(hipStreamSynchronize(stream));
+        *count_host = h[0];
+        if (h[1]) return MS3D_E_UNSUPPORTED;
     }
     return 0;
 }

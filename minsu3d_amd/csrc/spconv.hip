@@ -31,6 +31,14 @@ namespace {
 
 constexpr int MAX_NBT = 8;             // column blocks (of 16) a wave accumulates
 constexpr size_t LDS_BUDGET = 150 * 1024;
+// dynamic-LDS ceiling of a kernel = the CU's 160 KB minus what the kernel declares statically
+static hipError_t raise_lds_ceiling(const void *fn)
+{
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+}
 
 struct ConvArgs {
     const float *in;         // [Vin, Cin]
@@ -452,15 +460,15 @@ int launch_fwd_small(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool
 template <int NBT>
 int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
 {
+    // the dynamic-LDS ceiling of a kernel is raised ONCE, to the most any launch may ask for (per launch it would be a
+    // race between host threads that use different sizes)
     if (aligned) {
-        if (lds > 64 * 1024)
-            MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_kernel<NBT, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_kernel<NBT, true>);
+        MS3D_CHECK(attr);
         spconv_fwd_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
     } else {
-        if (lds > 64 * 1024)
-            MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_kernel<NBT, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_kernel<NBT, false>);
+        MS3D_CHECK(attr);
         spconv_fwd_kernel<NBT, false><<<grid, threads, lds, stream>>>(p);
     }
     MS3D_LAUNCH_CHECK();
@@ -778,9 +786,8 @@ template <int NBT, int NCH>
 int launch_fwd_pairlist(ConvArgs p, dim3 grid, int threads, size_t lds, hipStream_t stream)
 {
     p.ntiles = ms3d_divup(p.Vout, CR);
-    if (lds > 64 * 1024)
-        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_fwd_pairlist_kernel<NBT, NCH>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_pairlist_kernel<NBT, NCH>);
+    MS3D_CHECK(attr);
     spconv_fwd_pairlist_kernel<NBT, NCH><<<grid, threads, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
@@ -1133,9 +1140,8 @@ int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t strea
     if (nw > 16) nw = 16;
     dim3 grid(nblk_rows, 1, ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
     const size_t lds = (size_t)nw * per_wave;
-    if (lds > 64 * 1024)
-        MS3D_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>);
+    MS3D_CHECK(attr);
     spconv_wgrad_offsetlist_kernel<NBT, NCH><<<grid, nw * 64, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;

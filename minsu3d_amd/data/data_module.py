@@ -70,13 +70,21 @@ class DataModule:
         if stage in ("predict",):
             self.test_set = GeneralDataset(self.cfg, "test", self.elastic_fn)
 
-    def _loader(self, dataset, batch_size, shuffle):
+    def _loader(self, dataset, batch_size, shuffle, epoch=0):
         # samples are host arrays; the device work (quantisation) happens in the collate call of the consuming process
-        return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=0,
-                          collate_fn=partial(sparse_collate_fn, device=self.device, voxel_size=self.cfg.data.voxel_size))
+        collate = partial(sparse_collate_fn, device=self.device, voxel_size=self.cfg.data.voxel_size)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one process per GPU: every rank draws disjoint, size-matched scenes (the reference gets its sharding from
+            # Lightning's automatic DistributedSampler, config/model/base.yaml:13-16)
+            from ..parallel import BalancedDistributedBatchSampler
+            sizes = [len(sc["xyz"]) for sc in dataset.scenes]
+            sampler = BalancedDistributedBatchSampler(sizes, batch_size, shuffle=shuffle)
+            sampler.set_epoch(epoch)
+            return DataLoader(dataset, batch_sampler=sampler, num_workers=0, collate_fn=collate)
+        return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=0, collate_fn=collate)
 
-    def train_dataloader(self):
-        return self._loader(self.train_set, self.cfg.data.batch_size, True)
+    def train_dataloader(self, epoch=0):
+        return self._loader(self.train_set, self.cfg.data.batch_size, True, epoch)
 
     def val_dataloader(self):
         return self._loader(self.val_set, 1, False)

@@ -58,16 +58,33 @@ def predicted_instances(model, data_dict, output_dict):
                                      output_dict["cls_scores"], output_dict["iou_scores"], output_dict["mask_scores"], n_ign)
 
 
+def _dist():
+    d = torch.distributed
+    return d if d.is_available() and d.is_initialized() and d.get_world_size() > 1 else None
+
+
 class Trainer:
+    """One process per GPU (torchrun): the model is wrapped in DistributedDataParallel, every rank trains on its own
+    size-matched shard of each step's scenes (data_module.py), validation is sharded too and reduced on rank 0, which
+    also writes the checkpoints -- the reference's `strategy: ddp` (config/model/base.yaml:13-16)."""
+
     def __init__(self, cfg, model, datamodule, out_dir=None, log=print):
         self.cfg, self.model, self.dm, self.log = cfg, model, datamodule, log
         self.out_dir = out_dir or os.path.join(cfg.exp_output_root_path, "training")
         self.optimizer = model.configure_optimizers()
         self.global_step = 0
         self.history = []
+        self.rank = _dist().get_rank() if _dist() else 0
+        from .parallel import wrap_ddp
+        dev = next(model.parameters()).device
+        self.ddp = wrap_ddp(model, dev, find_unused_parameters=True)   # the score branch idles until prepare_epochs
 
     def validate(self):
         model, cfg = self.model, self.cfg
+        dist = _dist()
+        if dist:
+            from .parallel import sync_buffers
+            sync_buffers(model)          # every rank evaluates with rank 0's BatchNorm statistics
         model.eval()
         losses, acc, miou, preds, gts, boxes = [], [], [], [], [], []
         with torch.no_grad():
@@ -86,6 +103,10 @@ class Trainer:
                         preds.append(inst)
                         boxes.append(get_gt_bbox(xyz, ids.numpy(), sem.numpy(), -1, cfg.data.ignore_classes))
                         gts.append(get_gt_instances(sem.clone(), ids.clone(), cfg.data.ignore_classes))
+        if dist:      # the shards of the validation split meet on every rank (small host objects: RLE masks, boxes)
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, (losses, acc, miou, preds, gts, boxes))
+            losses, acc, miou, preds, gts, boxes = ([x for p in parts for x in p[i]] for i in range(6))
         res = {"val/total_loss": float(np.mean(losses)), "val_eval/semantic_accuracy": float(np.mean(acc)),
                "val_eval/semantic_mean_iou": float(np.mean(miou))}
         if preds:
@@ -114,12 +135,19 @@ class Trainer:
         for epoch in range(start, max_epochs):
             model.current_epoch = epoch
             total, n = 0.0, 0
-            batches = iter(self.dm.train_dataloader())
+            try:
+                loader = self.dm.train_dataloader(epoch)     # rank-sharded samplers reshuffle per epoch
+            except TypeError:
+                loader = self.dm.train_dataloader()
+            batches = iter(loader)
             batch = next(batches, None)
             while batch is not None:
                 upcoming = next(batches, None)      # collated (on the GPU) one step ahead
                 opt.zero_grad(set_to_none=True)
-                loss = model.training_step(batch)
+                if self.ddp is model:
+                    loss = model.training_step(batch)
+                else:                               # through the DDP wrapper: it arms the gradient all-reduce
+                    loss = sum(model._loss(batch, self.ddp(batch)).values())
                 if upcoming is not None and torch.is_tensor(upcoming.get("voxel_xyz")):
                     # coordinate-only structures of the next batch, built under this step's backward pass
                     ME.prefetch_coordinates(upcoming["voxel_xyz"], model.backbone.n_levels)
@@ -133,7 +161,11 @@ class Trainer:
             rec = {"epoch": epoch, "train/total_loss": total / max(n, 1), "lr": opt.param_groups[0]["lr"]}
             if (epoch + 1) % every == 0:
                 rec.update(self.validate())
-                save_checkpoint(os.path.join(self.out_dir, f"epoch={epoch}.ckpt"), model, opt, epoch, self.global_step)
+                if self.rank == 0:
+                    save_checkpoint(os.path.join(self.out_dir, f"epoch={epoch}.ckpt"), model, opt, epoch, self.global_step)
+                if _dist():
+                    _dist().barrier()
             self.history.append(rec)
-            self.log(rec)
+            if self.rank == 0:
+                self.log(rec)
         return self.history

@@ -36,13 +36,71 @@ def shard_scene_seeds(step, scenes_per_rank, rank, world_size):
 
 
 def wrap_ddp(model, device, find_unused_parameters=True):
-    """DistributedDataParallel with the reference's setting (unused heads before `prepare_epochs` get no grad ->
-    find_unused_parameters; callers that know every parameter is used -- grouping branch on -- pass False and skip
-    the per-step graph traversal).  25 MB buckets overlap the all-reduce with the rest of backward; per-rank BatchNorm
-    statistics are NOT synchronised, exactly like the reference (no SyncBN)."""
+    """DistributedDataParallel (unused heads before `prepare_epochs` get no grad -> find_unused_parameters; callers
+    that know every parameter is used -- grouping branch on -- pass False and skip the per-step graph traversal).
+    25 MB buckets overlap the all-reduce with the rest of backward.  BatchNorm statistics are per rank, like the
+    reference (no SyncBN).  One deliberate difference: the reference runs Lightning DDP with torch's default
+    broadcast_buffers=True, i.e. rank 0's BatchNorm running statistics are broadcast at EVERY forward; here the
+    buffers are left alone during training (80 BatchNorm layers x 3 buffers per step for values only evaluation reads)
+    and `sync_buffers()` broadcasts rank 0's before validation and before a checkpoint is written, which is where the
+    reference's ranks > 0 would see them."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return model
-    ids = None if device is None else [device.index]
+    ids = None if device is None or device.type != "cuda" else [device.index]
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
                                                      broadcast_buffers=False, bucket_cap_mb=25,
                                                      gradient_as_bucket_view=True)
+
+
+def sync_buffers(model, src=0):
+    """rank `src`'s buffers (BatchNorm running_mean / running_var / num_batches_tracked) to every rank"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for m in model.modules():
+        flush = getattr(m, "flush_batches_tracked", None)      # host-side counter of MinkowskiBatchNorm
+        if flush is not None:
+            flush()
+    for b in model.buffers():
+        dist.broadcast(b, src)
+
+
+class BalancedDistributedBatchSampler(torch.utils.data.Sampler):
+    """Rank-sharded batches (what Lightning's automatic DistributedSampler gives the reference,
+    data_module.py:23-39) with the scenes of one step SIZE-MATCHED across ranks: a step lasts as long as its slowest
+    rank, and scene sizes (hence ball-query / BFS / convolution work) spread over 2-3x in ScanNet.  Per epoch: one
+    seeded permutation (identical on every rank) is cut into windows of world*batch*window_steps scenes; inside a window
+    the scenes are sorted by size and dealt out as consecutive batches -- batch j to rank j % world in step j // world --
+    so the ranks of a step hold neighbours in the size order; the steps of a window are then shuffled again.  Like
+    DistributedSampler the tail is padded by wrap-around so that every rank runs the same number of steps."""
+
+    def __init__(self, sizes, batch_size, rank=None, world_size=None, shuffle=True, seed=0, window_steps=8):
+        self.sizes = [int(s) for s in sizes]
+        self.batch_size = int(batch_size)
+        self.rank = dist.get_rank() if rank is None and dist.is_initialized() else int(rank or 0)
+        self.world = dist.get_world_size() if world_size is None and dist.is_initialized() else int(world_size or 1)
+        self.shuffle, self.seed, self.window_steps, self.epoch = shuffle, seed, window_steps, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        per_step = self.batch_size * self.world
+        return (len(self.sizes) + per_step - 1) // per_step
+
+    def __iter__(self):
+        n = len(self.sizes)
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        order = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
+        per_step = self.batch_size * self.world
+        total = len(self) * per_step
+        order = (order * (total // max(n, 1) + 1))[:total]               # wrap-around padding
+        win = per_step * self.window_steps
+        steps = []
+        for w0 in range(0, total, win):
+            chunk = sorted(order[w0:w0 + win], key=lambda i: (self.sizes[i], i))
+            wsteps = [chunk[s:s + per_step] for s in range(0, len(chunk), per_step)]
+            if self.shuffle:
+                wsteps = [wsteps[i] for i in torch.randperm(len(wsteps), generator=g).tolist()]
+            steps.extend(wsteps)
+        for st in steps:                                                   # scenes of a step, ascending size:
+            yield st[self.rank::self.world]                                # rank r takes every world-th one

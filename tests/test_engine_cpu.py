@@ -62,3 +62,98 @@ def test_fit_checkpoint_resume(dataset_dir, tmp_path):  # noqa: F811
     fresh = build(cfg, seed=5)
     assert load_checkpoint(str(tmp_path / "ref_style.ckpt"), fresh) == (-1, 0)
     assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), m_full.state_dict().values()))
+
+
+def test_balanced_sampler_shards_and_matches_sizes():
+    """every scene once per epoch (up to the wrap-around padding), disjoint across ranks inside a step, and the scenes of
+    one step are neighbours in the size order (a step lasts as long as its largest rank)"""
+    from minsu3d_amd.parallel import BalancedDistributedBatchSampler
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(40_000, 260_000, 203).tolist()
+    world, bs = 4, 2
+    per_rank = []
+    for r in range(world):
+        s = BalancedDistributedBatchSampler(sizes, bs, rank=r, world_size=world, seed=3)
+        s.set_epoch(5)
+        per_rank.append(list(s))
+    steps = len(per_rank[0])
+    assert steps == -(-203 // (world * bs)) and all(len(p) == steps for p in per_rank)
+    seen = [i for p in per_rank for b in p for i in b]
+    assert set(seen) == set(range(203)) and len(seen) == steps * world * bs
+    spread = []
+    for t in range(steps):
+        batches = [per_rank[r][t] for r in range(world)]
+        flat = [i for b in batches for i in b]
+        assert len(set(flat)) == len(flat) or t == steps - 1              # disjoint (the padded last step may repeat)
+        load = [sum(sizes[i] for i in b) for b in batches]
+        spread.append(max(load) / (sum(load) / world))
+    naive = []
+    order = np.random.default_rng(1).permutation(203)[:steps * world * bs // 1].tolist()
+    for t in range(steps - 1):
+        load = [sum(sizes[i] for i in order[(t * world + r) * bs:(t * world + r + 1) * bs]) for r in range(world)]
+        naive.append(max(load) / (sum(load) / world))
+    assert np.mean(spread) < 1.08 < np.mean(naive)                        # slowest rank within 8 % of the mean (random: ~30 %)
+    s2 = BalancedDistributedBatchSampler(sizes, bs, rank=0, world_size=world, seed=3)
+    s2.set_epoch(6)
+    assert list(s2) != per_rank[0]                                        # reshuffled per epoch
+    s2.set_epoch(5)
+    assert list(s2) == per_rank[0]                                        # and reproducible
+
+
+def _fit_worker(rank, world, port, root, out_dir, q):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import torch.distributed as dist
+    ms_backend.set_backend(OracleBackend())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    over = {"data.batch_size": 1, "model.network.m": 8, "model.network.blocks": "[1,2]", "model.network.prepare_epochs": 0,
+            "model.trainer.check_val_every_n_epoch": 1, "model.trainer.max_epochs": 2, "data.augmentation.elastic": False}
+    cfg = make_cfg(root, **over)
+    np.random.seed(rank); torch.manual_seed(0)                 # same initial weights, different augmentation draws
+    model = build(cfg)
+    dm = DataModule(cfg, device="cpu"); dm.setup("fit")
+    seen = []
+    orig = dm.train_dataloader
+    def tracked(epoch=0):
+        loader = orig(epoch)
+        seen.append([list(b) for b in loader.batch_sampler])
+        return loader
+    dm.train_dataloader = tracked
+    tr = Trainer(cfg, model, dm, out_dir=out_dir, log=lambda r: None)
+    hist = tr.fit(max_epochs=2)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    q.put((rank, seen, [r["train/total_loss"] for r in hist], hist[-1].get("val_eval/semantic_mean_iou"),
+           {k: v.double().sum().item() for k, v in state.items()}))
+    dist.destroy_process_group()
+
+
+def test_trainer_fit_ddp_world_size_2_gloo(dataset_dir, tmp_path):  # noqa: F811
+    """config 5's loop on 2 ranks (gloo, CPU oracle backend): rank-sharded scenes, gradients all-reduced by DDP, BatchNorm
+    buffers taken from rank 0 for validation / checkpoints, one checkpoint per epoch written by rank 0"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    out_dir = str(tmp_path / "ddp")
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, str(dataset_dir), out_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, seen0, loss0, miou0, st0), (_, seen1, loss1, miou1, st1) = res
+    assert len(seen0) == 2 and len(seen0[0]) == len(seen1[0]) == 2           # 3 scenes, 2 ranks, batch 1 -> 2 steps (padded)
+    for e in range(2):
+        for b0, b1 in zip(seen0[e][:1], seen1[e][:1]):
+            assert set(b0).isdisjoint(b1)                                       # the ranks of a step hold different scenes
+        assert {i for b in seen0[e] + seen1[e] for i in b} == {0, 1, 2}
+    assert seen0[0] != seen0[1] or seen1[0] != seen1[1]                         # reshuffled per epoch
+    assert all(np.isfinite(loss0)) and all(np.isfinite(loss1)) and loss0 != loss1   # different data per rank
+    assert miou0 == miou1                                                       # validation reduced over the ranks
+    assert st0.keys() == st1.keys()
+    for k in st0:                                                               # same weights AND same BN buffers
+        assert st0[k] == pytest.approx(st1[k], rel=1e-6, abs=1e-9), k
+    assert sorted(os.listdir(out_dir)) == ["epoch=0.ckpt", "epoch=1.ckpt"]

@@ -193,3 +193,23 @@ def test_softgroup_step_cpu(cpu_backend):
     assert torch.isfinite(total)
     total.backward()
     assert model.iou_score.weight.grad is not None and model.tiny_unet.unet[0].blocks.block0.conv_branch[2].kernel.grad.abs().sum() > 0
+
+
+def test_batchnorm_counter_and_cumulative_momentum(cpu_backend):
+    """num_batches_tracked is counted on the host and flushed when read; a loaded state replaces (not adds to) it;
+    momentum=None is torch's cumulative moving average"""
+    import minsu3d_amd.MinkowskiEngine as ME
+    torch.manual_seed(0)
+    coords = torch.cat([torch.zeros(50, 1, dtype=torch.int32), torch.arange(150, dtype=torch.int32).view(50, 3)], 1)
+    x = [ME.SparseTensor(features=torch.randn(50, 4) * (i + 1), coordinates=coords) for i in range(3)]
+    bn, ref = ME.MinkowskiBatchNorm(4, momentum=None), torch.nn.BatchNorm1d(4, momentum=None)
+    for t in x:
+        bn(t).features
+        ref(t.features)
+    assert torch.allclose(bn.bn.running_mean, ref.running_mean, atol=1e-6) and torch.allclose(bn.bn.running_var, ref.running_var, rtol=1e-5)
+    sd = bn.state_dict()
+    assert int(sd["bn.num_batches_tracked"]) == 3
+    bn2 = ME.MinkowskiBatchNorm(4)
+    bn2(x[0]).features                      # one pending batch on the fresh instance ...
+    bn2.load_state_dict(sd)                 # ... which the loaded count replaces
+    assert int(bn2.state_dict()["bn.num_batches_tracked"]) == 3

@@ -377,3 +377,18 @@ def test_adjoint_identities_at_bench_size(be, cin, cout, level):
     y2 = be.conv_forward(x2, wf, nbr, V, K, cin, cout)
     y12 = be.conv_forward(x + 2 * x2, wf, nbr, V, K, cin, cout)
     assert rel_err(y12.cpu(), (y + 2 * y2).cpu()) < RTOL
+
+
+def test_out_of_range_coordinates_are_rejected(be):
+    """the 64-bit voxel key holds 15 bits per axis and 19 for the batch / cluster id: a coordinate that does not fit must
+    not silently alias another voxel"""
+    from minsu3d_amd._lib import HipLibraryError
+    c = torch.tensor([[0, 1, 2, 3], [0, 5, 6, 7], [1, 20000, 0, 0]], dtype=torch.int32, device="cuda")
+    with pytest.raises(HipLibraryError, match="10002"):
+        be.sparse_quantize(c)
+    c[2, 1] = 100
+    uniq, inv = be.sparse_quantize(c)
+    assert uniq.tolist() == [0, 1, 2]
+    c[1, 0] = 600000
+    with pytest.raises(HipLibraryError, match="10002"):
+        be.downsample(c, 1)
