@@ -82,7 +82,8 @@ def train_step(model, ddp, opt, batch, next_batch=None):
     if next_batch is not None:
         # input pipelining, as a data loader would do it: the coordinate-only work of the NEXT batch (row order, kernel
         # maps, pair lists) is built on a side stream while this step's backward pass runs
-        ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False)
+        ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
+                                channels=model.backbone.level_channels)
     loss.backward()
     opt.step()
     return loss

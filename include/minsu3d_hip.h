@@ -175,6 +175,13 @@ int ms3d_kmap_pairlist_header_ints(int Vout);
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout);
 int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
                              size_t workspace_bytes /* >= ms3d_coord_workspace_bytes(1) */, ms3d_stream_t stream);
+/* The same list with tiles of rows_per_tile = 64 (above) or 128 output rows: the convolution kernel for layers with more
+ * than 32 channels on a side reads its weights from L2 once per run of batches with the same offset, and a 128-row tile
+ * has ~3 batches per offset where a 64-row tile has ~1.5 (and pads 2 % of its slots instead of 25 %). */
+int ms3d_kmap_pairlist_header_ints_rows(int Vout, int rows_per_tile);
+size_t ms3d_kmap_pairlist_capacity_rows(int K, int Vout, int rows_per_tile);
+int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_tile, int *tile_start, int *entries,
+                                  void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
 
 /* Offset-major pair list of a table (the classic per-offset in/out index pairs) for the backward-weight kernel:
  *   kt_start[header_ints]    K * tiles + 1 pair offsets: first pair of (offset k, 64-row tile t) at [k * tiles + t],
@@ -193,12 +200,17 @@ int ms3d_morton_keys(const int *coords, int V, long long *keys, ms3d_stream_t st
 /* weights W[K][Cin][Cout] -> MFMA-fragment order.  transpose=1 (+mirror=1 for k3) gives the backward-data
  * operator: Weff[k] = W[mirror ? K-1-k : k]^T with Cin_eff = Cout, Cout_eff = Cin. */
 size_t ms3d_spconv_wf_floats(int K, int Cin_eff, int Cout_eff);
+/* wf_stream (same size as wf, or NULL): the same weights in "streamed" order, read 16 bytes per lane straight from L2 by
+ * the kernels for layers whose weights do not fit LDS (more than 32 channels on a side, pair-listed tables) */
 int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, int transpose, int mirror, float *wf,
-                             ms3d_stream_t stream);
+                             float *wf_stream, ms3d_stream_t stream);
 /* out[i,:] = sum_k act(in[nbr[k][i],:]) @ Weff[k] (+ residual); act = optional x*pre_scale+pre_shift (+ReLU).
  * With bn_x != NULL the epilogue is the backward of a fused BN+ReLU: out = dz = acc * [bn_x*bn_scale+bn_shift > 0]
  * and bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block sums of dz and dz*xhat. */
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist);
+/* rows per tile of the pair list a forward / backward-data convolution of this shape wants in pl_tile_start / pl_entries:
+ * 0 = none, 64 = ms3d_kmap_pairlist_build, 128 = ms3d_kmap_pairlist_build_rows(.., 128, ..) */
+int ms3d_spconv_pairlist_rows(int Vout, int K, int Cin, int Cout);
 /* 1 when the convolution kernels have a pair-list variant worth building the list for (full-resolution levels) */
 int ms3d_kmap_pairlist_wanted(int K, int Vout);
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
@@ -207,14 +219,18 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
                         const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
                         const float *bias /* [Cout] or NULL */,
                         const int *pl_tile_start /* pair list of `nbr` (ms3d_kmap_pairlist_build) or NULL */,
-                        const int *pl_entries, ms3d_stream_t stream);
+                        const int *pl_entries,
+                        const float *wf_stream /* streamed image of the same weights; required when a pair list is given
+                                                  and a side has more than 32 channels, NULL otherwise */,
+                        ms3d_stream_t stream);
 /* out_stats != 0 (forward only): bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block
  * (sum, sum of squares) of the OUTPUT rows (after the residual add) -> feed ms3d_bn_finalize, no extra pass. */
 int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
-                                  ms3d_stream_t stream);
+                                  float *wf_stream /* or NULL */, float *wft_stream /* or NULL */, ms3d_stream_t stream);
 /* Both images of n layers in ONE launch (a U-Net re-lays ~90 weight tensors per step, ~5 us of dispatch each).
  * descs: device array of n 48-byte records {const float *W; float *wf; float *wft; int K, Cin, Cout, mirror_bwd,
- * block_begin, 0}, block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum. */
+ * block_begin, 0}, block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum.
+ * wf and wft each have room for 2 * ms3d_spconv_wf_floats() floats: the image, then its streamed form. */
 int ms3d_spconv_prep_blocks(int K, int Cin, int Cout);
 int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, ms3d_stream_t stream);
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
@@ -229,7 +245,8 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
                                 const int *ol_kt_start /* offset list of `nbr` (ms3d_kmap_offsetlist_build) or NULL */,
                                 const int *ol_entries, ms3d_stream_t stream);
 /* One-call layer entry points (forward / backward of a fused [BN -> ReLU ->] conv): same kernels as above, enqueued
- * from native code.  wf_buf holds both weight images (ms3d_spconv_wf_floats(K,Cin,Cout)+(K,Cout,Cin) floats) and is
+ * from native code.  wf_buf holds both weight images, each followed by its streamed form
+ * (4 * ms3d_spconv_wf_floats(K,Cin,Cout) floats: [wf | wf streamed | wft | wft streamed]) and is
  * kept by the caller between forward and backward; ws: ms3d_spconv_layer_ws_floats() floats of scratch.
  * layer_forward with W == NULL skips the re-lay: wf_buf already holds the current images (prep_weights_multi). */
 size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout);

@@ -79,13 +79,15 @@ class CoordinateManager:
 _PREFETCHED = {}   # (data_ptr, shape) of a coordinate tensor -> (future of (manager, cuda event), the tensor itself)
 
 
-def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True):
+def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channels=None):
     """Input pipelining (not part of ME's API): build everything that depends on the COORDINATES of a batch the next
     forward will use -- engine row order, the coordinate sets and kernel maps of `n_levels` U-Net levels, their pair
     lists -- on the helper thread and a side stream, e.g. while the current step's backward pass keeps the GPU busy and
     the interpreter idle.  `SparseTensor(features, coordinates)` picks the result up when it is given the same tensor.
     wait_current_stream=False: the coordinates are known to be complete (a resident batch), the side stream need not
-    wait for the work queued on the caller's stream."""
+    wait for the work queued on the caller's stream.  channels: the channel width of every level (the pair list a
+    convolution walks depends on it: 128-row tiles above 32 channels); without it the 16 / 32-channel lists are built and
+    a wider level builds its own on first use."""
     if not coordinates.is_cuda or os.environ.get("MS3D_PREFETCH_COORDS", "1") == "0":
         return
     key = (coordinates.data_ptr(), tuple(coordinates.shape))
@@ -104,13 +106,15 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True):
             ts = 1
             for lvl in range(n_levels):          # the lists the convolutions of these levels will ask for
                 nbr, v = cm.k3(ts), cm.size(ts)
-                be.pairlist(nbr, 27, v)
+                c = channels[lvl] if channels is not None else 16
+                be.pairlist(nbr, 27, v, c, c)
                 be.offsetlist(nbr, 27, v)
                 if lvl + 1 < n_levels:
                     down, up = cm.k2(ts)
                     vc = cm.size(2 * ts)
-                    be.pairlist(down, 8, vc); be.offsetlist(down, 8, vc)
-                    be.pairlist(up, 8, v); be.offsetlist(up, 8, v)
+                    c2 = channels[lvl + 1] if channels is not None else 16
+                    be.pairlist(down, 8, vc, c, c2); be.pairlist(down, 8, vc, c2, c); be.offsetlist(down, 8, vc)
+                    be.pairlist(up, 8, v, c2, c); be.pairlist(up, 8, v, c, c2); be.offsetlist(up, 8, v)
                 ts *= 2
             ev = torch.cuda.Event()
             ev.record(side)
@@ -137,8 +141,9 @@ def _take_prefetched(coordinates):
         held.append(ext)     # an int32 copy made on the side stream (the caller's coordinates had another dtype)
     for t in list(held):
         if t is not None:
-            for attr in ("_ms3d_pairlist", "_ms3d_offsetlist"):
-                held.extend(x for x in (getattr(t, attr, None) or ()) if x is not None)
+            for pl in (getattr(t, "_ms3d_pairlist", None) or {}).values():      # {rows per tile: (tile_start, entries)}
+                held.extend(x for x in pl if x is not None)
+            held.extend(x for x in (getattr(t, "_ms3d_offsetlist", None) or ()) if x is not None)
     for t in held:
         if t is not None and t.is_cuda:
             t.record_stream(cur)

@@ -472,12 +472,13 @@ class _HipEngine:
 
     # ---- convolution
     def prep_weights(self, W, K, cin_e, cout_e, transpose=False, mirror=False):
+        """-> weight image handle [2, n]: row 0 the fragment-major image, row 1 the same weights in streamed order"""
         W = self._dev(W)
         self.lib.ms3d_spconv_wf_floats.restype = C.c_size_t
         nfl = self.lib.ms3d_spconv_wf_floats(int(K), int(cin_e), int(cout_e))
-        wf = torch.empty(nfl, dtype=torch.float32, device=W.device)
+        wf = torch.empty((2, nfl), dtype=torch.float32, device=W.device)
         _lib.check(self.lib.ms3d_spconv_prep_weights(_lib.ptr(W), int(K), int(cin_e), int(cout_e), int(transpose),
-                                                     int(mirror), _lib.ptr(wf), _lib.stream_handle()),
+                                                     int(mirror), _lib.ptr(wf[0]), _lib.ptr(wf[1]), _lib.stream_handle()),
                    "ms3d_spconv_prep_weights")
         return wf
 
@@ -485,12 +486,12 @@ class _HipEngine:
         """forward image and backward-data image (W^T, offsets mirrored for k3) in one launch"""
         W = self._dev(W)
         self.lib.ms3d_spconv_wf_floats.restype = C.c_size_t
-        n1 = self.lib.ms3d_spconv_wf_floats(int(K), int(cin), int(cout))
-        n2 = self.lib.ms3d_spconv_wf_floats(int(K), int(cout), int(cin))
-        buf = torch.empty(n1 + n2, dtype=torch.float32, device=W.device)
-        wf, wft = buf[:n1], buf[n1:]
+        n = self.lib.ms3d_spconv_wf_floats(int(K), int(cin), int(cout))    # == wf_floats(K, cout, cin)
+        buf = torch.empty((2, 2, n), dtype=torch.float32, device=W.device)
+        wf, wft = buf[0], buf[1]                                             # each [2, n]: image, streamed image
         _lib.check(self.lib.ms3d_spconv_prep_weights_pair(_lib.ptr(W), int(K), int(cin), int(cout), int(mirror_bwd),
-                                                          _lib.ptr(wf), _lib.ptr(wft), _lib.stream_handle()),
+                                                          _lib.ptr(wf[0]), _lib.ptr(wft[0]), _lib.ptr(wf[1]),
+                                                          _lib.ptr(wft[1]), _lib.stream_handle()),
                    "ms3d_spconv_prep_weights_pair")
         return wf, wft
 
@@ -506,24 +507,29 @@ class _HipEngine:
             self._ident[(n, device)] = t
         return t
 
-    def pairlist(self, nbr, K, vout):
-        """tile-compacted pair list of an offset-major table, built on first use and cached on the table tensor
-        (every convolution of a level shares it) -> (tile_start, entries) or (None, None) for small levels"""
-        pl = getattr(nbr, "_ms3d_pairlist", None)
+    def pairlist(self, nbr, K, vout, cin=16, cout=16):
+        """tile-compacted pair list of an offset-major table for a convolution of this shape, built on first use and cached
+        on the table tensor (every convolution of a level shares it) -> (tile_start, entries) or (None, None) when the
+        shape takes a kernel that walks the table itself.  Layers with more than 32 channels on a side want 128-row
+        tiles, the others 64-row tiles (ms3d_spconv_pairlist_rows)."""
+        rows = self._geom("ms3d_spconv_pairlist_rows", vout, K, cin, cout)
+        if rows == 0:
+            return (None, None)
+        cache = getattr(nbr, "_ms3d_pairlist", None)
+        if cache is None:
+            cache = nbr._ms3d_pairlist = {}
+        pl = cache.get(rows)
         if pl is None:
-            pl = (None, None)
-            if self.lib.ms3d_kmap_pairlist_wanted(int(K), int(vout)):
-                self.lib.ms3d_kmap_pairlist_capacity.restype = C.c_size_t
-                cap = self.lib.ms3d_kmap_pairlist_capacity(int(K), int(vout))
-                tile_start = torch.empty(self.lib.ms3d_kmap_pairlist_header_ints(int(vout)), dtype=torch.int32,
-                                         device=nbr.device)
-                entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
-                ws = self._cws(1, nbr.device)
-                _lib.check(self.lib.ms3d_kmap_pairlist_build(_lib.ptr(nbr), int(K), int(vout), _lib.ptr(tile_start),
-                                                             _lib.ptr(entries), _lib.ptr(ws), C.c_size_t(ws.numel()),
-                                                             _lib.stream_handle()), "ms3d_kmap_pairlist_build")
-                pl = (tile_start, entries)
-            nbr._ms3d_pairlist = pl
+            self.lib.ms3d_kmap_pairlist_capacity_rows.restype = C.c_size_t
+            cap = self.lib.ms3d_kmap_pairlist_capacity_rows(int(K), int(vout), rows)
+            tile_start = torch.empty(self.lib.ms3d_kmap_pairlist_header_ints_rows(int(vout), rows), dtype=torch.int32,
+                                     device=nbr.device)
+            entries = torch.empty((cap, 2), dtype=torch.int32, device=nbr.device)
+            ws = self._cws(1, nbr.device)
+            _lib.check(self.lib.ms3d_kmap_pairlist_build_rows(_lib.ptr(nbr), int(K), int(vout), rows, _lib.ptr(tile_start),
+                                                              _lib.ptr(entries), _lib.ptr(ws), C.c_size_t(ws.numel()),
+                                                              _lib.stream_handle()), "ms3d_kmap_pairlist_build_rows")
+            pl = cache[rows] = (tile_start, entries)
         return pl
 
     def offsetlist(self, nbr, K, vout):
@@ -557,17 +563,18 @@ class _HipEngine:
         ps, pb = (pre if pre is not None else (None, None))
         partial = None
         bnargs = [None] * 5
-        pl = self.pairlist(nbr, K, vout)
+        pl = self.pairlist(nbr, K, vout, cin, cout)
         if bn_bwd is not None or out_stats:
             nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), int(pl[0] is not None))
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
         if bn_bwd is not None:
             bnargs = [_f32(t) for t in bn_bwd]
         _lib.check(self.lib.ms3d_spconv_forward(
-            _lib.ptr(x), _lib.ptr(wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
+            _lib.ptr(x), _lib.ptr(wf[0] if wf.dim() == 2 else wf), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(out),
             _lib.ptr(_f32(ps)), _lib.ptr(_f32(pb)), int(bool(pre_relu)), _lib.ptr(_f32(residual)),
             *[_lib.ptr(t) for t in bnargs], _lib.ptr(partial), int(bool(out_stats)), _lib.ptr(_f32(bias)),
-            _lib.ptr(pl[0]), _lib.ptr(pl[1]), _lib.stream_handle()), "ms3d_spconv_forward")
+            _lib.ptr(pl[0]), _lib.ptr(pl[1]), _lib.ptr(wf[1]) if wf.dim() == 2 else None,
+            _lib.stream_handle()), "ms3d_spconv_forward")
         if bn_bwd is None:
             return (out, partial) if out_stats else out
         s1s2 = torch.empty((2, cout), dtype=torch.float32, device=x.device)
@@ -635,7 +642,8 @@ class _HipEngine:
         return v
 
     def wf_floats(self, K, cin, cout):
-        return self._geom("ms3d_spconv_wf_floats", K, cin, cout) + self._geom("ms3d_spconv_wf_floats", K, cout, cin)
+        """floats of a layer's weight buffer: forward and backward-data image, each followed by its streamed form"""
+        return 4 * self._geom("ms3d_spconv_wf_floats", K, cin, cout)
 
     def prep_weights_multi(self, layers):
         """layers: [(W [K,cin,cout] parameter, wf_buf, K, cin, cout, mirror_bwd)] -> both weight images of every layer in
@@ -653,7 +661,7 @@ class _HipEngine:
             begin = 0
             for i, (w, b, K, cin, cout, m) in enumerate(layers):
                 assert w.is_contiguous() and w.dtype == torch.float32 and b.numel() >= self.wf_floats(K, cin, cout)
-                rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
+                rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * 2 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
                           K, cin, cout, int(bool(m)), begin, 0)
                 begin += self.lib.ms3d_spconv_prep_blocks(int(K), int(cin), int(cout))
             table = torch.from_numpy(rec.view(np.uint8).copy()).to(layers[0][0].device)
@@ -674,7 +682,7 @@ class _HipEngine:
         wf_buf = wf_ready if wf_ready is not None else torch.empty(self.wf_floats(K, cin, cout), dtype=torch.float32, device=dev)
         y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
         stats = None
-        pl = self.pairlist(nbr_fwd, K, vout)
+        pl = self.pairlist(nbr_fwd, K, vout, cin, cout)
         if want_stats:
             nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, int(pl[0] is not None))
             stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev)
@@ -700,7 +708,7 @@ class _HipEngine:
         dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
         plf = self.offsetlist(nbr_fwd, K, vout)
-        plb = self.pairlist(nbr_bwd, K, vin) if want_dx else (None, None)
+        plb = self.pairlist(nbr_bwd, K, vin, cout, cin) if want_dx else (None, None)
         timer = self.kernel_timer
         tok = timer.conv("fwd", K, cout, cin, nbr_bwd, vin) if (timer is not None and want_dx) else None
         ev0, ev1 = tok if tok is not None else (None, None)

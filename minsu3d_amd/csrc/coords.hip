@@ -229,46 +229,66 @@ int rank_first(CoordWs &w, int n, int *count_host, hipStream_t stream)
 // One wave per tile of MS3D_PL_ROWS output rows.  Per offset the valid (input row, output row) pairs of the tile are
 // compacted with a ballot and padded to a multiple of 16 (a "batch": one MFMA group in the convolution kernels).
 // entry = (input row, (k << 8) | local output row); pad entries read input row 0 and carry local row MS3D_PL_ROWS.
-template <int KT>
+// RPT = rows per tile: 64 (one row per lane) or 128 (lane l owns rows l and 64 + l; the pairs of the lower half come
+// first inside an (offset) group, both halves in ascending row)
+template <int KT, int RPT>
 __global__ __launch_bounds__(256) void pairlist_count_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
                                                              int *__restrict__ tile_nb)
 {
+    constexpr int H = RPT / 64;
     const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
     if (tile > tiles) return;
     if (tile == tiles) {  // slot for the grand total of the exclusive scan
         if (lane_id() == 0) tile_nb[tiles] = 0;
         return;
     }
-    const int row = tile * MS3D_PL_ROWS + lane_id();
-    const bool ok = row < Vout;
-    int v[KT];
-#pragma unroll
-    for (int k = 0; k < KT; k++) v[k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
     int nb = 0;
+    int cnt[KT];
 #pragma unroll
-    for (int k = 0; k < KT; k++) nb += (__popcll(__ballot(v[k] >= 0)) + 15) >> 4;
+    for (int k = 0; k < KT; k++) cnt[k] = 0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        const int row = tile * RPT + 64 * h + lane_id();
+        const bool ok = row < Vout;
+#pragma unroll
+        for (int k = 0; k < KT; k++) {
+            const int v = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+            cnt[k] += __popcll(__ballot(v >= 0));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; k++) nb += (cnt[k] + 15) >> 4;
     if (lane_id() == 0) tile_nb[tile] = nb;
 }
 
-template <int KT>
+template <int KT, int RPT>
 __global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
                                                             const int *__restrict__ tile_start, int2 *__restrict__ entries)
 {
+    constexpr int H = RPT / 64;
     const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
     if (tile >= tiles) return;
     const int l = lane_id();
-    const int row = tile * MS3D_PL_ROWS + l;
-    const bool ok = row < Vout;
-    int v[KT];
+    int v[H][KT];   // all table entries of the tile first (one round trip), then the compaction
 #pragma unroll
-    for (int k = 0; k < KT; k++) v[k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+    for (int h = 0; h < H; h++) {
+        const int row = tile * RPT + 64 * h + l;
+        const bool ok = row < Vout;
+#pragma unroll
+        for (int k = 0; k < KT; k++) v[h][k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
+    }
     size_t base = (size_t)tile_start[tile] * 16;
 #pragma unroll
     for (int k = 0; k < KT; k++) {
-        const unsigned long long m = __ballot(v[k] >= 0);
-        const int n = __popcll(m), n16 = (n + 15) & ~15;
-        if (v[k] >= 0) entries[base + ballot_rank(m)] = make_int2(v[k], (k << 8) | l);
-        if (l < n16 - n) entries[base + n + l] = make_int2(0, (k << 8) | MS3D_PL_ROWS);
+        int n = 0;
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            const unsigned long long m = __ballot(v[h][k] >= 0);
+            if (v[h][k] >= 0) entries[base + n + ballot_rank(m)] = make_int2(v[h][k], (k << 8) | (64 * h + l));
+            n += __popcll(m);
+        }
+        const int n16 = (n + 15) & ~15;
+        if (l < n16 - n) entries[base + n + l] = make_int2(0, (k << 8) | RPT);
         base += n16;
     }
 }
@@ -470,31 +490,37 @@ int ms3d_kmap_pairlist_tiles(int Vout) { return ms3d_divup(Vout, MS3D_PL_ROWS); 
 
 // ints of the tile_start array: tiles + 1 batch offsets, part_start[MS3D_PL_PARTS + 1], (pad to 16 bytes,) the pick
 // list int4[tiles] = (tile, first batch, end batch, 0)
-int ms3d_kmap_pairlist_header_ints(int Vout)
+int ms3d_kmap_pairlist_header_ints_rows(int Vout, int rows_per_tile)
 {
-    const int tiles = ms3d_divup(Vout, MS3D_PL_ROWS);
+    const int tiles = ms3d_divup(Vout, rows_per_tile);
     return MS3D_PL_SCHED_OFFSET(tiles) + 4 * tiles;
 }
+int ms3d_kmap_pairlist_header_ints(int Vout) { return ms3d_kmap_pairlist_header_ints_rows(Vout, MS3D_PL_ROWS); }
 
-size_t ms3d_kmap_pairlist_capacity(int K, int Vout)
+size_t ms3d_kmap_pairlist_capacity_rows(int K, int Vout, int rows_per_tile)
 {
     // every (tile, offset) group pads by < 16 entries; + one group of slack (an empty last tile still reads its first slots)
-    return (size_t)K * ((size_t)Vout + 15 * (size_t)ms3d_divup(Vout, MS3D_PL_ROWS)) + 128;
+    return (size_t)K * ((size_t)Vout + 15 * (size_t)ms3d_divup(Vout, rows_per_tile)) + 128;
 }
+size_t ms3d_kmap_pairlist_capacity(int K, int Vout) { return ms3d_kmap_pairlist_capacity_rows(K, Vout, MS3D_PL_ROWS); }
 
-int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
-                             size_t workspace_bytes, ms3d_stream_t stream_)
+int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_tile, int *tile_start, int *entries,
+                                  void *workspace, size_t workspace_bytes, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
-    if (K > 27) return MS3D_E_UNSUPPORTED;
+    if (K > 27 || (rows_per_tile != 64 && rows_per_tile != 128)) return MS3D_E_UNSUPPORTED;
     if (workspace_bytes < ms3d_scan_workspace_bytes()) return MS3D_E_WORKSPACE;
-    const int tiles = ms3d_divup(Vout, MS3D_PL_ROWS);
+    const int tiles = ms3d_divup(Vout, rows_per_tile);
     const int grid = ms3d_divup((long)(tiles + 1) * 64, 256);
-    if (K <= 8)
-        pairlist_count_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
-    else
-        pairlist_count_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+    const bool wide = rows_per_tile == 128;
+    if (K <= 8) {
+        if (wide) pairlist_count_kernel<8, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+        else pairlist_count_kernel<8, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+    } else {
+        if (wide) pairlist_count_kernel<27, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+        else pairlist_count_kernel<27, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+    }
     MS3D_LAUNCH_CHECK();
     int rc = ms3d_exclusive_scan_i32(tile_start, tile_start, tiles + 1, nullptr, workspace, stream);
     if (rc) return rc;
@@ -504,12 +530,22 @@ int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, i
     MS3D_LAUNCH_CHECK();
     pairlist_order_kernel<<<MS3D_PL_PARTS, 64, 0, stream>>>(tile_start, part_start, order);
     MS3D_LAUNCH_CHECK();
-    if (K <= 8)
-        pairlist_fill_kernel<8><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
-    else
-        pairlist_fill_kernel<27><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, reinterpret_cast<int2 *>(entries));
+    int2 *ent = reinterpret_cast<int2 *>(entries);
+    if (K <= 8) {
+        if (wide) pairlist_fill_kernel<8, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+        else pairlist_fill_kernel<8, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+    } else {
+        if (wide) pairlist_fill_kernel<27, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+        else pairlist_fill_kernel<27, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+    }
     MS3D_LAUNCH_CHECK();
     return 0;
+}
+
+int ms3d_kmap_pairlist_build(const int *nbr, int K, int Vout, int *tile_start, int *entries, void *workspace,
+                             size_t workspace_bytes, ms3d_stream_t stream)
+{
+    return ms3d_kmap_pairlist_build_rows(nbr, K, Vout, MS3D_PL_ROWS, tile_start, entries, workspace, workspace_bytes, stream);
 }
 
 // ints of the kt_start array: K * tiles + 1 pair offsets, part_start[MS3D_PL_PARTS + 1], pair prefix per tile [tiles + 1]

@@ -43,6 +43,8 @@ static hipError_t raise_lds_ceiling(const void *fn)
 struct ConvArgs {
     const float *in;         // [Vin, Cin]
     const float *wf;         // fragment-major weights
+    const float *wfs;        // the same weights in streamed order (prep_weights_kernel) or null
+    int dbg;                 // MS3D_PS_DBG experiments (timing only, wrong results): 1 no MFMA, 2 no accumulate, 4 no weight loads, 8 no row gathers
     const int *nbr;          // [K][Vout]
     float *out;              // [Vout, Cout]
     const float *pre_scale;  // [Cin] or null : a = max(0, x*scale + shift)
@@ -70,9 +72,21 @@ struct ConvArgs {
 
 // ------------------------------------------------------------------ weight permutation
 // Wf[((k*NCH + ch)*4 + t)*NBtot + nb][lane] = Weff[k][c = 16ch + 4q + t][j = 16nb + (lane & 15)],  q = lane >> 4
+// The STREAMED image holds the same numbers with the four steps t of a lane next to each other,
+//     Wfs[((k*NCH + ch)*NBtot + nb)*64 + lane][t],
+// so that a kernel that reads its weights straight from L2 fetches them 16 bytes per lane (spconv_fwd_pairstream_kernel).
+__device__ __forceinline__ long stream_slot(long o, int NBtot)
+{
+    const int lane = (int)(o & 63);
+    long r = o >> 6;
+    const int nb = (int)(r % NBtot); r /= NBtot;
+    const int t = (int)(r & 3); r >>= 2;   // r = k*NCH + ch
+    return ((r * NBtot + nb) * 64 + lane) * 4 + t;
+}
+
 __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restrict__ wf, int K, int Cin_e, int Cout_e,
                                     int NCH, int NBtot, int transpose, int mirror, float *__restrict__ wf2, int NCH2,
-                                    int NBtot2, int mirror2)
+                                    int NBtot2, int mirror2, float *__restrict__ wfs, float *__restrict__ wfs2)
 {
     const long total = (long)K * NCH * 4 * NBtot * 64;
     if (wf2) {
@@ -87,7 +101,9 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
             const int k = (int)(r / NCH2);
             const int c = 16 * ch + 4 * (lane >> 4) + t, j = 16 * nb + (lane & 15);  // c < Cout_e, j < Cin_e
             const int ks = mirror2 ? (K - 1 - k) : k;
-            wf2[o] = (c < Cout_e && j < Cin_e) ? W[((size_t)ks * Cin_e + j) * Cout_e + c] : 0.f;
+            const float v = (c < Cout_e && j < Cin_e) ? W[((size_t)ks * Cin_e + j) * Cout_e + c] : 0.f;
+            wf2[o] = v;
+            if (wfs2) wfs2[stream_slot(o, NBtot2)] = v;
         }
     }
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -104,6 +120,7 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
             v = transpose ? W[((size_t)ks * Cout_e + j) * Cin_e + c]   // original layout [K][Cout_e(=Cin_o)][Cin_e(=Cout_o)]
                           : W[((size_t)ks * Cin_e + c) * Cout_e + j];
         wf[o] = v;
+        if (wfs) wfs[stream_slot(o, NBtot)] = v;
     }
 }
 
@@ -111,7 +128,8 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
 // KB of work, and a U-Net has ~90 of them per step.  descs[i].block_begin = first workgroup of layer i.
 struct PrepDesc {
     const float *W;   // [K][Cin][Cout]
-    float *wf, *wft;  // forward image, backward-data image (transposed, offsets mirrored if mirror_bwd)
+    float *wf, *wft;  // forward image, backward-data image (transposed, offsets mirrored if mirror_bwd);
+                      // each is followed by its streamed image: wf + n, wft + n  (n = ms3d_spconv_wf_floats)
     int K, Cin, Cout, mirror_bwd, block_begin, pad;
 };
 static_assert(sizeof(PrepDesc) == 48, "layout shared with the host-side descriptor table");
@@ -135,7 +153,9 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int t = (int)(r & 3); r >>= 2;
         const int ch = (int)(r % NCH), k = (int)(r / NCH);
         const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;
-        d.wf[o] = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
+        const float v = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
+        d.wf[o] = v;
+        d.wf[total + stream_slot(o, NB)] = v;
     }
     {
         long r = o >> 6;
@@ -144,7 +164,9 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int ch = (int)(r % NB), k = (int)(r / NB);
         const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;  // c < Cout, j < Cin
         const int ks = d.mirror_bwd ? (d.K - 1 - k) : k;
-        d.wft[o] = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
+        const float v = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
+        d.wft[o] = v;
+        d.wft[total + stream_slot(o, NCH)] = v;
     }
 }
 
@@ -793,6 +815,329 @@ int launch_fwd_pairlist(ConvArgs p, dim3 grid, int threads, size_t lds, hipStrea
     return 0;
 }
 
+
+// ------------------------------------------------------------------ pair-list forward / backward-data, 48+ channels
+// The pair-list idea (above) for layers whose weights do not fit LDS (27 x 64 x 64 x 4 B = 442 KB).  The table walk is
+// MFMA-bound there -- on work that multiplies absent neighbours (10 of 27 offsets valid per row at level 1: 2.6x the
+// useful flops).  Here a wave owns a 128-row tile of the WIDE pair list (ms3d_kmap_pairlist_build_rows(.., 128, ..):
+// ~3 batches per offset, 2 % pad slots) with its accumulator tile in LDS, and streams everything else from L2 into the
+// registers the MFMAs consume:
+//   * weights: a batch's offset is wave-uniform; the fragments of (offset, channel group) come from the STREAMED image
+//     (prep_weights_kernel) 16 bytes per lane, once per run of batches with that offset;
+//   * work unit ("stage") = up to two batches of one offset x one group of CG 16-channel input chunks
+//     = 2 x CG x 4 x NBT MFMAs (128 at 64 -> 64: 4096 matrix-pipe cycles);
+//   * software pipeline, one wave per SIMD: while stage s multiplies, the weights and rows of stage s+1 and the pair
+//     entries of the chunk after that are in flight (the loads of a stage are issued one stage early, weights first, so
+//     the MFMAs never wait for anything younger than what they need); the tile's chunk list (offset, first batch,
+//     batch count) is derived once per tile from the entries and kept in LDS.
+// Deterministic like the other kernels: batches in ascending offset order, one writer per accumulator tile.
+constexpr int PSR = 128;  // rows per tile of the wide pair list
+constexpr int PSW = 4;    // floats of padding per accumulator row: 16 rows x one 16-byte chunk spread over all 64 banks
+constexpr int PSCH = 224; // chunk-list slots per wave (a 128-row tile has at most 27 * 8 = 216 batches)
+
+__host__ __device__ constexpr size_t pairstream_wave_floats(int nbt) { return PSCH + (size_t)(PSR + 1) * (nbt * 16 + PSW); }
+
+template <int NBT, int CG>
+__global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    constexpr int CW = NBT * 16, RS = CW + PSW;  // accumulator row width / stride
+    constexpr int F4 = CW / 4;                    // 16-byte chunks per row
+    constexpr int RPS = 64 / F4;                  // rows the wave streams out per epilogue step
+    const int l = lane_id(), q = l >> 4, jl = l & 15;
+    const int waves = blockDim.x >> 6;
+    const int nb0 = blockIdx.y * NBT;
+    const int NG = p.NCH / CG;                    // channel groups (the launcher guarantees NCH % CG == 0)
+    float *s_part = lds;                          // [2*Cout]
+    int *s_next = reinterpret_cast<int *>(s_part + ((2 * p.Cout + 3) & ~3));
+    float *s_pre = s_part + ((2 * p.Cout + 3) & ~3) + 4;   // [2][Cin]: scale, shift of the fused input BatchNorm
+    float *wave_base = s_pre + ((2 * p.Cin + 3) & ~3) + (size_t)wave_id() * pairstream_wave_floats(NBT);
+    int *s_chunks = reinterpret_cast<int *>(wave_base);    // (first batch) | (batches << 16) | (offset << 24)
+    float *acc_t = wave_base + PSCH;                       // [(PSR + 1)][RS]
+
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // blocks of one XCD take neighbouring tiles
+    if (nblk % 8 != 0) vb = blockIdx.x;
+    const int *__restrict__ part_start = p.pl_tile_start + p.ntiles + 1;
+    const int4 *__restrict__ picks = reinterpret_cast<const int4 *>(p.pl_tile_start + MS3D_PL_SCHED_OFFSET(p.ntiles));
+    const int2 *__restrict__ entries = reinterpret_cast<const int2 *>(p.pl_entries);
+    const f32x4 *__restrict__ wfs4 = reinterpret_cast<const f32x4 *>(p.wfs);
+    const int t0 = part_start[vb], nmine = part_start[vb + 1] - t0;
+    int slot = wave_id();
+    int4 desc = picks[min(t0 + min(slot, max(nmine - 1, 0)), p.ntiles - 1)];
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (threadIdx.x == 0) *s_next = waves;
+    if (p.pre_scale)
+        for (int c = threadIdx.x; c < p.Cin; c += blockDim.x) {
+            s_pre[c] = p.pre_scale[c];
+            s_pre[p.Cin + c] = p.pre_shift[c];
+        }
+    for (int e = l; e < (PSR + 1) * RS / 4; e += 64) reinterpret_cast<f32x4 *>(acc_t)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};  // per-lane column sums (columns 4*(l % F4)..+3)
+    const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
+    const bool ep_lane = l < RPS * F4;
+
+    while (slot < nmine) {
+        int next_slot = 0;
+        if (l == 0) next_slot = atomicAdd(s_next, 1);
+        const int tile = __builtin_amdgcn_readfirstlane(desc.x);
+        const int row0 = tile * PSR;
+        const int b_begin = __builtin_amdgcn_readfirstlane(desc.y);
+        const int nbatch = min(__builtin_amdgcn_readfirstlane(desc.z) - b_begin, PSCH);
+        const int2 *__restrict__ tile_entries = entries + (size_t)b_begin * 16;
+        next_slot = __builtin_amdgcn_readfirstlane(next_slot);
+        const int4 next_desc = picks[t0 + min(next_slot, nmine - 1)];
+
+        // ---- chunk list of the tile: runs of batches with one offset, cut into chunks of <= 2 batches
+        int nchunks = 0;
+        {
+            int kb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gi = l + 64 * j;
+                kb[j] = gi < nbatch ? (tile_entries[(size_t)gi * 16].y >> 8) : 255;
+            }
+            int carry_k = -1, carry_rs = -1;   // offset of the batch before this register's first lane / its run start
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gi = l + 64 * j;
+                int prev = __shfl_up(kb[j], 1, 64);
+                if (l == 0) prev = carry_k;
+                int nxtk = __shfl_down(kb[j], 1, 64);
+                const int first_next = j < 3 ? __builtin_amdgcn_readlane(kb[j < 3 ? j + 1 : 3], 0) : 255;
+                if (l == 63) nxtk = first_next;
+                const bool run_start = gi < nbatch && kb[j] != prev;
+                int rs = run_start ? gi : -1;  // inclusive max-scan: start of the run this batch belongs to
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(rs, d, 64);
+                    if (l >= d) rs = max(rs, o);
+                }
+                rs = max(rs, carry_rs);
+                const bool chunk_start = gi < nbatch && ((gi - rs) & 1) == 0;
+                const int n = (gi + 1 < nbatch && nxtk == kb[j]) ? 2 : 1;
+                const unsigned long long m = __ballot(chunk_start);
+                if (chunk_start) s_chunks[nchunks + ballot_rank(m)] = gi | (n << 16) | (kb[j] << 24);
+                nchunks += __popcll(m);
+                carry_k = __builtin_amdgcn_readlane(kb[j], 63);
+                carry_rs = __builtin_amdgcn_readlane(rs, 63);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        const int S = nchunks * NG;
+        if (S > 0) {
+            auto chunk_at = [&](int ci) { return __builtin_amdgcn_readfirstlane(s_chunks[min(ci, nchunks - 1)]); };
+            auto load_entries = [&](int info) {
+                const int c = info & 0xFFFF, n = (info >> 16) & 0xFF;
+                return tile_entries[(size_t)(c + min((l >> 4) & 1, n - 1)) * 16 + jl];
+            };
+            auto load_w = [&](int k, int g, f32x4 (&w)[CG][NBT]) {
+                if (p.dbg & 4) k = 0;
+#pragma unroll
+                for (int ch = 0; ch < CG; ch++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++)
+                        w[ch][nb] = wfs4[((size_t)(k * p.NCH + g * CG + ch) * p.NBtot + nb0 + nb) * 64 + l];
+            };
+            auto gather = [&](const int2 &e, int g, f32x4 (&a)[2][CG]) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    int in_row = __builtin_amdgcn_ds_bpermute((i * 16 + jl) << 2, e.x);
+                    if (p.dbg & 8) in_row = jl;
+                    const float *row = p.in + (size_t)in_row * (size_t)p.Cin + 16 * g * CG + 4 * q;
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++) a[i][ch] = *reinterpret_cast<const f32x4 *>(row + 16 * ch);
+                }
+            };
+            int info = chunk_at(0), info1 = chunk_at(1);
+            int2 e_cur = load_entries(info), e_nxt = load_entries(info1), e_nxt2 = e_nxt;
+            f32x4 w_cur[CG][NBT], w_nxt[CG][NBT], a_cur[2][CG], a_nxt[2][CG], d[2][NBT];
+            load_w(info >> 24, 0, w_cur);
+            gather(e_cur, 0, a_cur);
+            int ci = 0, g = 0;
+            for (int s = 0; s < S; s++) {
+                const int n = (info >> 16) & 0xFF, k = info >> 24;
+                const bool last_g = g == NG - 1;
+                // ---- requests of the next stage: weights first, then rows, then the entries of the chunk after next
+                const int g1 = last_g ? 0 : g + 1;
+                const int k1 = last_g ? (info1 >> 24) : k;
+                // (every stage issues the SAME loads -- the weights again even when the next chunk continues this offset,
+                // the entries again for every channel group: a load behind a branch makes the wait in front of the MFMAs
+                // cover the shorter path, i.e. wait for loads of THIS stage, and the pipeline is gone)
+                load_w(k1, g1, w_nxt);
+                gather(last_g ? e_nxt : e_cur, g1, a_nxt);
+                e_nxt2 = load_entries(chunk_at(ci + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- this stage
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++) d[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (p.pre_scale) {
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++) {
+                        const int c0 = 16 * (g * CG + ch) + 4 * q;
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(s_pre + c0);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(s_pre + p.Cin + c0);
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                const float x = fmaf(a_cur[i][ch][t], sc[t], sh[t]);
+                                a_cur[i][ch][t] = p.pre_relu ? fmaxf(x, 0.f) : x;
+                            }
+                    }
+                }
+                if (!(p.dbg & 1)) {
+#pragma unroll
+                for (int ch = 0; ch < CG; ch++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++)
+                            d[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[ch][nb][t], a_cur[0][ch][t], d[0][nb], 0, 0, 0);
+                }
+                if (n > 1 && !(p.dbg & 1)) {
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int nb = 0; nb < NBT; nb++)
+                                d[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[ch][nb][t], a_cur[1][ch][t], d[1][nb], 0, 0, 0);
+                }
+                if (last_g && !(p.dbg & 2)) {
+                    // D^T layout: row = output channel 4q + r, column = pair jl -> 16 contiguous bytes of the pair's row;
+                    // plain read-modify-write (one writer per tile, LDS operations execute in order, pads -> dummy row)
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        if (i >= n) break;
+                        const int orow = __builtin_amdgcn_ds_bpermute((i * 16 + jl) << 2, e_cur.y) & 255;
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++) {
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(acc_t + orow * RS + 16 * nb + 4 * q);
+                            f32x4 c = *dst;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) c[r] += d[i][nb][r];
+                            *dst = c;
+                        }
+                    }
+                }
+                // ---- rotate the pipeline registers
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++) a_cur[i][ch] = a_nxt[i][ch];
+#pragma unroll
+                for (int ch = 0; ch < CG; ch++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) w_cur[ch][nb] = w_nxt[ch][nb];
+                if (last_g) {
+                    ci++;
+                    g = 0;
+                    info = info1;
+                    info1 = chunk_at(ci + 1);
+                    e_cur = e_nxt;
+                    e_nxt = e_nxt2;
+                } else {
+                    g++;
+                }
+            }
+        }
+        slot = next_slot;
+        desc = next_desc;
+        __builtin_amdgcn_wave_barrier();
+        // ---- epilogue: PSR x CW accumulator tile, row-major, 16 B per lane per step
+        for (int r0 = 0; r0 < PSR; r0 += RPS) {
+            const int r = r0 + l / F4;
+            if (!ep_lane || r >= PSR) continue;
+            f32x4 *src = reinterpret_cast<f32x4 *>(acc_t + r * RS + 4 * c4);
+            f32x4 o4 = *src;
+            *src = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = row0 + r;
+            if (row < p.Vout) {
+                const size_t o = (size_t)row * p.Cout + col;
+                if (p.residual) {
+                    const f32x4 rs = *reinterpret_cast<const f32x4 *>(p.residual + o);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o4[t] += rs[t];
+                }
+                if (p.bias) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o4[t] += p.bias[col + t];
+                }
+                if (p.bn_x) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(p.bn_x + o);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float z = fmaf(x[t], p.bn_scale[col + t], p.bn_shift[col + t]);
+                        const float gz = (z > 0.f) ? o4[t] : 0.f;
+                        o4[t] = gz;
+                        st1[t] += gz;
+                        st2[t] += gz * ((x[t] - p.bn_mean[col + t]) * p.bn_invstd[col + t]);
+                    }
+                } else if (p.out_stats) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        st1[t] += o4[t];
+                        st2[t] = fmaf(o4[t], o4[t], st2[t]);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(p.out + o) = o4;
+            }
+        }
+        // the dummy row collected the pad products; clear it with the rest
+        if (l < F4) reinterpret_cast<f32x4 *>(acc_t + PSR * RS)[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (with_partial) {
+        // lanes with equal l % F4 hold the same 4 columns (F4 need not be a power of two): through the wave's idle
+        // accumulator tile, lane-major, then F4 lanes add the RPS copies up in a fixed order
+        float *scr = acc_t;                       // [64][8] per-lane sums, then [2][CW] wave sums behind them
+        *reinterpret_cast<f32x4 *>(scr + 8 * l) = ep_lane ? st1 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(scr + 8 * l + 4) = ep_lane ? st2 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+        if (l < F4) {
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+            for (int j = 0; j < RPS; j++) {
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(scr + 8 * (l + j * F4));
+                const f32x4 v2 = *reinterpret_cast<const f32x4 *>(scr + 8 * (l + j * F4) + 4);
+#pragma unroll
+                for (int t = 0; t < 4; t++) { a1[t] += v1[t]; a2[t] += v2[t]; }
+            }
+            *reinterpret_cast<f32x4 *>(scr + 512 + 4 * l) = a1;
+            *reinterpret_cast<f32x4 *>(scr + 512 + CW + 4 * l) = a2;
+        }
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        const float *wave0 = s_pre + ((2 * p.Cin + 3) & ~3) + PSCH + 512;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) {
+            const int which = t >= p.Cout, c = t - which * p.Cout - 16 * nb0;  // column inside this block's slice
+            float sum = 0.f;
+            if (c >= 0 && c < CW)
+                for (int wv = 0; wv < waves; wv++) sum += wave0[(size_t)wv * pairstream_wave_floats(NBT) + which * CW + c];
+            dst[t] = sum;
+        }
+    }
+}
+
+template <int NBT, int CG>
+int launch_fwd_pairstream(ConvArgs p, dim3 grid, int threads, size_t lds, hipStream_t stream)
+{
+    p.ntiles = ms3d_divup(p.Vout, PSR);
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_pairstream_kernel<NBT, CG>);
+    MS3D_CHECK(attr);
+    spconv_fwd_pairstream_kernel<NBT, CG><<<grid, threads, lds, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ backward-weight
 struct WgradArgs {
     const float *in;         // [Vin, Cin]
@@ -1345,26 +1690,26 @@ size_t ms3d_spconv_wf_floats(int K, int Cin, int Cout)
 }
 
 int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, int transpose, int mirror, float *wf,
-                             ms3d_stream_t stream)
+                             float *wf_stream, ms3d_stream_t stream)
 {
     const int NCH = ms3d_divup(Cin_eff, 16), NBtot = ms3d_divup(Cout_eff, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64;
     prep_weights_kernel<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
-        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror, nullptr, 0, 0, 0);
+        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror, nullptr, 0, 0, 0, wf_stream, nullptr);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
 
 // forward image wf (W[K][Cin][Cout]) and backward-data image wft (W^T, optionally offset-mirrored) in ONE launch
 int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
-                                  ms3d_stream_t stream)
+                                  float *wf_stream, float *wft_stream, ms3d_stream_t stream)
 {
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int NCH2 = ms3d_divup(Cout, 16), NBtot2 = ms3d_divup(Cin, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64, total2 = (long)K * NCH2 * 4 * NBtot2 * 64;
     const long m = total > total2 ? total : total2;
     prep_weights_kernel<<<(int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
-        W, wf, K, Cin, Cout, NCH, NBtot, 0, 0, wft, NCH2, NBtot2, mirror_bwd);
+        W, wf, K, Cin, Cout, NCH, NBtot, 0, 0, wft, NCH2, NBtot2, mirror_bwd, wf_stream, wft_stream);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1394,7 +1739,8 @@ namespace {
 struct FwdGeom {
     int nbt, ny, threads, nblk, G;
     size_t lds;
-    bool ok, small, pairlist;
+    bool ok, small, pairlist, stream;
+    int cg;   // stream kernel: 16-channel chunks per weight group
 };
 constexpr int PAIRLIST_MIN_ROWS = 30000;  // below this the 16-row kernels win (weight staging per block dominates)
 int pairlist_min_rows()
@@ -1405,11 +1751,35 @@ int pairlist_min_rows()
     }();
     return v;
 }
+int pairstream_mode()
+{
+    // 1 = rectangular layers above 32 channels stream their weights from L2 (spconv_fwd_pairstream_kernel); 3 = all
+    // layers above 32 channels do; 2 = up to 64 input channels take the LDS-resident pair-list kernel in 16-column
+    // slices instead; 0 = table walk
+    static const int v = [] { const char *e = getenv("MS3D_PAIRSTREAM"); return e ? atoi(e) : 1; }();
+    return v;
+}
 bool pairlist_shape_ok(int Vout, int K, int Cin, int Cout)
 {
     // Vout <= 2^22: the kernel addresses input rows with 32-bit element offsets (Vin <= 8 * Vout for a stride-2 map)
+    const bool wide_ok = pairstream_mode() == 2 && Cin <= 64 && Cout <= 256 && (size_t)Vout * 8 * Cin < (1ull << 32);
     return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && Vout <= (1 << 22) && K > 1 && K <= 27 &&
-           Cin % 16 == 0 && Cout % 16 == 0 && Cin <= 32 && Cout <= 32;
+           Cin % 16 == 0 && Cout % 16 == 0 && ((Cin <= 32 && Cout <= 32) || wide_ok);
+}
+// wide layers (a side above 32 channels) on pair-listed tables: weights streamed from L2 (spconv_fwd_pairstream_kernel).
+// Measured on the benchmark's tables (tools/conv_micro.py, us per launch, stream vs table walk): 64 -> 32 at level 0
+// 221 vs 417, 32 -> 64 238 vs 388, 128 -> 64 at level 1 647 vs 795, 64 -> 128 520 vs 940 -- but 64 -> 64 at level 1
+// 360 vs 384, 48 -> 48 at level 2 108 vs 85, 96 -> 96 326 vs 295: the square layers of the deeper levels have 10-12
+// of 27 neighbours per row and the table walk skips a tile's empty offsets, the kernel here pays ~340 non-MFMA
+// instructions and five dependent LDS / memory waits per 64-MFMA stage (SQ counters: 60 % of the wave cycles in issue
+// stalls) and does not overlap them with the matrix pipe.  So it takes the RECTANGULAR layers (the first convolution
+// after a concatenation and its backward-data twin), where the table walk's column-slice geometry is at its worst.
+bool pairstream_shape_ok(int Vout, int K, int Cin, int Cout)
+{
+    const int mode = pairstream_mode();   // 3 = every wide layer (experiments)
+    const bool on = (mode == 1 && Cin != Cout) || mode == 3 || (mode == 2 && Cin > 64);
+    return on && pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && Vout <= (1 << 22) && K > 1 && K <= 27 &&
+           Cin % 16 == 0 && Cout % 16 == 0 && (Cin > 32 || Cout > 32) && Cin <= 256 && Cout <= 256;
 }
 constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
@@ -1442,6 +1812,37 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         g.ok = ks <= 4 && g.nbt >= 1 && g.nbt <= MAX_NBT;
         return g;
     }
+    if (with_pairlist && pairstream_shape_ok(Vout, K, Cin, Cout)) {
+        // Column slices of at most two 16-column blocks: a 128-row accumulator tile is then <= 19 KB, EIGHT waves fit a CU
+        // -- two per SIMD, so one wave's loads / LDS updates / register shuffling issue under the other's MFMAs (with one
+        // wave per SIMD and 64-column tiles the compiler's straight-line MFMA blocks left the rest un-overlapped: 360 us
+        // at 64 -> 64 against 150 us of matrix-pipe time) -- at the price of gathering the input rows once per slice.
+        static const int env_nbt = [] { const char *e = getenv("MS3D_PS_NBT"); return e ? atoi(e) : 2; }();
+        static const int env_w = [] { const char *e = getenv("MS3D_PS_W"); return e ? atoi(e) : 8; }();
+        int nbt = 1, cg = 1;
+        for (int c = env_nbt; c >= 1; c--)
+            if (NBtot % c == 0) { nbt = c; break; }
+        for (int c = 4; c >= 1; c--)
+            if (NCH % c == 0) { cg = c; break; }
+        const int ny = NBtot / nbt;
+        const size_t spart = (size_t)(((2 * Cout + 3) & ~3) + 4 + ((2 * Cin + 3) & ~3)) * sizeof(float);
+        const size_t perwave = pairstream_wave_floats(nbt) * sizeof(float);
+        int W = env_w;
+        while (W > 1 && spart + (size_t)W * perwave > 158 * 1024) W--;
+        const int tiles = ms3d_divup(Vout, PSR);
+        const int wfill = ms3d_divup(tiles, MS3D_PL_PARTS);   // no more waves than a part has tiles
+        if (W > wfill) W = wfill < 1 ? 1 : wfill;
+        g.stream = true;
+        g.cg = cg;
+        g.ny = ny;
+        g.nbt = nbt;
+        g.threads = W * 64;
+        g.nblk = MS3D_PL_PARTS;
+        g.G = K;
+        g.lds = spart + (size_t)W * perwave;
+        g.ok = true;
+        return g;
+    }
     if (with_pairlist && pairlist_shape_ok(Vout, K, Cin, Cout)) {
         // column split (the gathers are repeated per slice) only when the weight image would starve the block of waves
         int nbt = NBtot;
@@ -1456,7 +1857,11 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
             return wbytes + spart >= LDS_BUDGET ? 0 : (int)((LDS_BUDGET - wbytes - spart) / perwave);
         };
         static const int min_waves = [] { const char *e = getenv("MS3D_PL_MIN_WAVES"); return e ? atoi(e) : 8; }();
-        while (nbt > 1 && nbt % 2 == 0 && waves_for(nbt) < min_waves) nbt /= 2;
+        while (nbt > 1 && waves_for(nbt) < min_waves) {   // next smaller divisor of the column-block count
+            int d = nbt - 1;
+            while (NBtot % d != 0) d--;
+            nbt = d;
+        }
         int W = waves_for(nbt);
         const int tiles = ms3d_divup(Vout, CR);
         if (W > 16) W = 16;
@@ -1520,6 +1925,14 @@ extern "C" {
 
 int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27; }
 
+// rows per tile of the pair list a forward / backward-data convolution of this shape walks: 0 = none (table walk /
+// small-level kernel), 64 = ms3d_kmap_pairlist_build, 128 = ms3d_kmap_pairlist_build_rows(.., 128, ..)
+int ms3d_spconv_pairlist_rows(int Vout, int K, int Cin, int Cout)
+{
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, false, true);
+    return g.stream ? PSR : (g.pairlist ? MS3D_PL_ROWS : 0);
+}
+
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist)
 {
     const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true, with_pairlist != 0);
@@ -1531,12 +1944,14 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
                         const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
-                        const float *bias, const int *pl_tile_start, const int *pl_entries, ms3d_stream_t stream_)
+                        const float *bias, const int *pl_tile_start, const int *pl_entries, const float *wf_stream,
+                        ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
     ConvArgs p;
     p.bias = bias;
+    p.wfs = nullptr;
     p.pl_tile_start = pl_tile_start; p.pl_entries = pl_entries;
     p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
@@ -1548,11 +1963,27 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
+    if (g.stream) {
+        if (!wf_stream) return MS3D_E_UNSUPPORTED;  // the geometry (and the caller's partial buffer) assume this kernel
+        p.wfs = wf_stream;
+        static const int dbg = [] { const char *e = getenv("MS3D_PS_DBG"); return e ? atoi(e) : 0; }();
+        p.dbg = dbg;
+#define MS3D_PS(NBT_, CG_) \
+    if (g.nbt == NBT_ && g.cg == CG_) return launch_fwd_pairstream<NBT_, CG_>(p, grid, g.threads, g.lds, stream);
+        MS3D_PS(1, 1) MS3D_PS(1, 2) MS3D_PS(1, 3) MS3D_PS(1, 4)
+        MS3D_PS(2, 1) MS3D_PS(2, 2) MS3D_PS(2, 3) MS3D_PS(2, 4)
+        MS3D_PS(3, 1) MS3D_PS(3, 2) MS3D_PS(3, 3) MS3D_PS(3, 4)
+        MS3D_PS(4, 1) MS3D_PS(4, 2) MS3D_PS(4, 3) MS3D_PS(4, 4)
+#undef MS3D_PS
+        return MS3D_E_UNSUPPORTED;
+    }
     if (g.pairlist) {
         if (g.nbt == 1 && p.NCH == 1) return launch_fwd_pairlist<1, 1>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 2) return launch_fwd_pairlist<1, 2>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 2 && p.NCH == 1) return launch_fwd_pairlist<2, 1>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 2 && p.NCH == 2) return launch_fwd_pairlist<2, 2>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 1 && p.NCH == 3) return launch_fwd_pairlist<1, 3>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 1 && p.NCH == 4) return launch_fwd_pairlist<1, 4>(p, grid, g.threads, g.lds, stream);
         return MS3D_E_UNSUPPORTED;
     }
     if (g.small) {
@@ -1758,14 +2189,15 @@ int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd
                               const int *pl_tile_start, const int *pl_entries, void *ev_start, void *ev_stop,
                               ms3d_stream_t stream)
 {
-    float *wf = wf_buf, *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
-    int rc = W ? ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, stream) : 0;  // W == NULL: wf_buf is current
+    const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);  // wf_buf = [wf | wf streamed | wft | wft streamed]
+    float *wf = wf_buf, *wft = wf_buf + 2 * nwf;
+    int rc = W ? ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, wf + nwf, wft + nwf, stream) : 0;  // W == NULL: wf_buf is current
     if (rc) return rc;
     // optional HIP events bracketing ONLY the convolution kernel, on the stream it is launched on (bench.py roofline)
     if (ev_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     rc = ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
                              nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, pl_tile_start,
-                             pl_entries, stream);
+                             pl_entries, wf + nwf, stream);
     if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return rc;
 }
@@ -1798,7 +2230,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
                                void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop, ms3d_stream_t stream)
 {
-    const float *wft = wf_buf + ms3d_spconv_wf_floats(K, Cin, Cout);
+    const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
+    const float *wft = wf_buf + 2 * nwf, *wfts = wf_buf + 3 * nwf;
     const bool bn = scale != nullptr;
     int rc;
     // optional HIP events bracketing ONLY the backward-data convolution kernel (bench.py roofline)
@@ -1806,7 +2239,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     if (need_dx || bn) {
         if (!bn) {
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
+                                     nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts,
+                                     stream);
             if (rc) return rc;
             if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
             ev_stop = nullptr;
@@ -1815,7 +2249,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, pl_bwd_tile_start && pl_bwd_entries);
             float *partial = ws;
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
-                                     mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, stream);
+                                     mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts, stream);
             if (rc) return rc;
             if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
             ev_stop = nullptr;

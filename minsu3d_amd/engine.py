@@ -150,7 +150,8 @@ class Trainer:
                     loss = sum(model._loss(batch, self.ddp(batch)).values())
                 if upcoming is not None and torch.is_tensor(upcoming.get("voxel_xyz")):
                     # coordinate-only structures of the next batch, built under this step's backward pass
-                    ME.prefetch_coordinates(upcoming["voxel_xyz"], model.backbone.n_levels)
+                    ME.prefetch_coordinates(upcoming["voxel_xyz"], model.backbone.n_levels,
+                                            channels=model.backbone.level_channels)
                 loss.backward()
                 opt.step()
                 batch = upcoming

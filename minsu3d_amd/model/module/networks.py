@@ -34,6 +34,7 @@ class Backbone(nn.Module):
         self.semantic_branch = _head(m, sem_classes)
         self.offset_branch = _head(m, 3)
         self.n_levels = len(block_channels)
+        self.level_channels = [m * c for c in block_channels]
 
     def forward(self, voxel_features, voxel_coordinates, v2p_map):
         x = ME.SparseTensor(features=voxel_features, coordinates=voxel_coordinates)

@@ -71,9 +71,13 @@ def test_conv_kernels_vs_oracle(be, oracle, cin, cout, K):
     _check_conv(be, oracle, cin, cout, K, 24000 if big else 3000, 60)
 
 
-@pytest.mark.parametrize("cin,cout,K", [(16, 16, 27), (32, 16, 27), (16, 32, 27), (16, 32, 8), (32, 32, 27), (32, 32, 8)])
+@pytest.mark.parametrize("cin,cout,K", [(16, 16, 27), (32, 16, 27), (16, 32, 27), (16, 32, 8), (32, 32, 27), (32, 32, 8),
+                                        # more than 32 channels on a side: weights streamed from L2
+                                        # (spconv_fwd_pairstream_kernel), every (column tile, channel group) shape class
+                                        (48, 48, 27), (64, 64, 27), (96, 96, 27), (64, 32, 27), (32, 64, 27), (80, 80, 27),
+                                        (128, 64, 27), (96, 64, 8), (64, 96, 8)])
 def test_conv_pair_compacted_kernels_vs_oracle(be, oracle, cin, cout, K):
-    """full-resolution sizes (>= 50k output rows) take the pair-compacted kernel (spconv_fwd_compact_kernel)"""
+    """full-resolution sizes (>= 50k output rows) take the pair-list kernels"""
     V = _check_conv(be, oracle, cin, cout, K, 200000 if K == 27 else 600000, 300 if K == 27 else 400)
     assert V >= 50000
 
@@ -267,7 +271,7 @@ def test_pair_lists_bit_exact(be, oracle, K, scene):
     V = nbr.shape[1]
     assert V >= 50000
     nbr_d = dev(nbr)
-    tile_start, entries = be.pairlist(nbr_d, K, V)
+    tile_start, entries = be.pairlist(nbr_d, K, V, 16, 16)
     kt_start, pairs = be.offsetlist(nbr_d, K, V)
     tiles = (V + 63) // 64
     # offset-major: exact pairs in (k, output row) order
@@ -344,10 +348,10 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
     token = be.weight_token
     be.prep_weights_multi(layers)
     assert be.weight_token == token + 1
-    for (W, buf, K, cin, cout, _), (wf, wft) in zip(layers, want):
-        assert torch.equal(buf[:wf.numel()], wf) and torch.equal(buf[wf.numel():], wft), (K, cin, cout)
+    for (W, buf, K, cin, cout, _), (wf, wft) in zip(layers, want):     # buffer = [wf | wf streamed | wft | wft streamed]
+        assert torch.equal(buf.view(2, 2, -1)[0], wf) and torch.equal(buf.view(2, 2, -1)[1], wft), (K, cin, cout)
     be.prep_weights_multi(layers[:2])          # a different set of tensors: the descriptor table is rebuilt
-    assert torch.equal(layers[1][1][:want[1][0].numel()], want[1][0])
+    assert torch.equal(layers[1][1].view(2, 2, -1)[0], want[1][0])
 
 
 @pytest.mark.parametrize("cin,cout,level", [(16, 16, 0), (32, 32, 1), (48, 48, 2)])

@@ -43,26 +43,3 @@ us_w = e0.elapsed_time(e1) / n * 1e3
 alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
 print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | wgrad {us_w:.1f} us"
       f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
-# layer-style launch (fused BN+ReLU prologue, residual, output statistics) timed by the in-library HIP events
-from minsu3d_amd.backend import KernelTimer
-tm = KernelTimer(lambda *a: True, be.lib, max_records=40); be.kernel_timer = tm
-scale = torch.rand(cin, device=dev) + 0.5; shift = torch.randn(cin, device=dev) * 0.1
-res = torch.randn(vout, cout, device=dev) if cin == cout else None
-def layer(pre, r, stats, label):
-    tm = KernelTimer(lambda *a: True, be.lib, max_records=40); be.kernel_timer = tm
-    for _ in range(3):
-        be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, pre, True, r, None, stats)
-    tm.enabled = True
-    for _ in range(20):
-        be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, pre, True, r, None, stats)
-    torch.cuda.synchronize()
-    s = tm.summary()
-    print(f"layer forward ({label}): events avg {s['avg_ms'] * 1e3:.1f} us over {s['launches']} launches")
-
-
-layer((scale, shift), res, True, "BN+ReLU prologue, residual, stats")
-if os.environ.get("CONV_MICRO_PARTS"):
-    layer(None, None, False, "plain")
-    layer((scale, shift), None, False, "prologue only")
-    layer(None, res, False, "residual only")
-    layer(None, None, True, "stats only")

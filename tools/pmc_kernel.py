@@ -1,10 +1,10 @@
-"""Average a rocprofv3 counter_collection.csv per kernel: python tools/pmc_kernel.py <csv> <kernel substring>"""
+"""average of every collected counter for the kernels whose name contains a substring
+usage: python tools/pmc_kernel.py <counter_collection.csv> <kernel substring>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-sub = sys.argv[2]
-agg = collections.defaultdict(lambda: [0, 0.0])
+agg = collections.defaultdict(list)
 for r in rows:
-    if sub in r['Kernel_Name']:
-        a = agg[r['Counter_Name']]; a[0] += 1; a[1] += float(r['Counter_Value'])
-for k, (n, v) in sorted(agg.items()):
-    print(f"{k:28s} n={n:4d} avg={v / n:16.1f}")
+    if sys.argv[2] in r["Kernel_Name"]:
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    print(f"{k:28s} {sum(v) / len(v):16.0f}  ({len(v)} launches)")
