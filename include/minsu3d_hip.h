@@ -21,6 +21,7 @@ extern "C" {
 
 #define MS3D_E_WORKSPACE 10001 /* workspace too small */
 #define MS3D_E_UNSUPPORTED 10002 /* shape outside what the kernels support */
+#define MS3D_E_INTERNAL 10003 /* an invariant of the algorithm does not hold (a bug): results are not to be used */
 
 typedef void *ms3d_stream_t; /* hipStream_t */
 

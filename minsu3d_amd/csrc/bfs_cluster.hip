@@ -81,7 +81,7 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b)
 // storm of 232 k singletons meeting each other in the hook kernel
 __global__ void bfs_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
                                 const int *__restrict__ start_len, int *parent, int *comp_size, int *visited, int *claim,
-                                int *cl_size, int *scratch_seed, int *counters)
+                                int *cl_size, int *scratch_seed, int *defi, int *counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
@@ -96,6 +96,8 @@ __global__ void bfs_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
         claim[i] = INT_BIG;
         cl_size[i] = 0;
         scratch_seed[i] = -1;  // "slot not written": the assembly may run before an incomplete expansion is detected
+        scratch_seed[N + i] = -1;
+        defi[i] = 0;
     }
     if (i < 16) counters[i] = 0;
 }
@@ -730,6 +732,338 @@ __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DIRECTED dense graphs (some list was cut at the 1000-neighbour cap, e.g. SoftGroup's r = 4 cm grouping): a weak
+// component may hold several clusters, found one after the other by the serial algorithm (seeds in ascending index
+// order, each cluster = what its seed reaches among the still unvisited points).  Restated without the order: a point
+// belongs to the cluster of its SMALLEST ANCESTOR (the smallest index that reaches it along directed edges, itself
+// included) -- that ancestor cannot have been taken by an earlier seed (the earlier seed would be a smaller ancestor),
+// so it becomes a seed, and no point on the path from it is taken earlier for the same reason.  Hence two stages, both
+// chip-wide:
+//   stage 1  the weak components (union-find) expanded from their roots, all at once.  The root IS the smallest
+//            ancestor of everything it reaches, so what the expansion reaches is a final cluster; on the benchmark's
+//            graphs most components are exhausted by it.
+//   stage 2  the points left over in the other components (a few hundred per blob: those that are in nobody's
+//            1000-lowest list): smallest-ancestor labels by min-propagation along the out-edges among the leftovers
+//            (their ancestors are leftovers too: anything reachable from a visited point was visited), cluster sizes by
+//            label, and a second expansion from every label that qualifies, following only same-label edges.
+// Round 1 replayed every capped graph with one workgroup per component (12.6 ms per SoftGroup step); replaying only the
+// components stage 1 does not exhaust still took 8 ms, because the replay pays a seed search per leftover singleton.
+// A directed graph cannot be pulled (a node does not know who points at it), so the claims are pushed:
+//   claim : frontier node p posts atomicMin(claim[j], p) on its unvisited, label-compatible out-neighbours (behind a
+//           plain read and a coherent re-read: the atomics are what costs) and keeps the posted edges as one 64-bit mask
+//           per 64-edge slice;
+//   win   : single-pass compaction of the edges that won (claim[j] == p) in (p, slot) order, as in the symmetric case.
+constexpr int DIR_TILE = 16;          // frontier positions per tile of the win kernel
+constexpr int MAX_SLICES = 16;        // 64-edge slices per list (1000-entry cap)
+
+__global__ void dir_init_kernel(const int *__restrict__ worklist, const int *__restrict__ comp_size, int *counters,
+                                int *F0, int *comp_base, int *done, int *seg_start, int *seg_cnt, int *claim)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nwork = counters[0];
+    if (w == 0) counters[6] = nwork;
+    if (w >= nwork) return;  // launched for the upper bound N
+    const int r = worklist[w];
+    F0[w] = r;
+    comp_base[r] = atomicAdd(&counters[2], comp_size[r]);
+    done[r] = 0;
+    seg_start[r] = w;
+    seg_cnt[r] = 1;
+    claim[r] = -1;  // the seed is visited
+}
+
+// first mask slot of a node's list: strictly increasing with the node, never shared between two nodes
+__device__ __forceinline__ long mask_slot(int st, int node) { return (long)(st >> 6) + node; }
+
+template <bool GROUPS>   // stage 2: an edge counts only inside one label group (root[] holds the labels then)
+__global__ __launch_bounds__(256) void dir_claim_kernel(
+    Thr thr, int level, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
+    const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ F, int *counters,
+    const int *__restrict__ worklist, const int *__restrict__ comp_base, const int *__restrict__ done_cur, int *done_next,
+    const int *__restrict__ seg_start_cur, int *seg_start_next, const int *__restrict__ seg_cnt_cur, int *seg_cnt_next,
+    int *claim, int *scratch_node, int *scratch_seed, unsigned long long *__restrict__ amask,
+    unsigned long long *tile_status)
+{
+    const int nF = counters[6 + (level & 1)];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    {
+        const int nwork = counters[0];
+        for (int w = gid; w < nwork; w += gsz) {
+            const int r = worklist[w];
+            done_next[r] = done_cur[r] + seg_cnt_cur[r];
+            seg_start_next[r] = INT_BIG;
+            seg_cnt_next[r] = 0;
+        }
+        const int ntiles = (nF + DIR_TILE - 1) / DIR_TILE;
+        for (int t = gid; t < ntiles; t += gsz) tile_status[t] = 0ull;
+        if (gid == 0) {
+            counters[8] = 0;
+            counters[6 + ((level + 1) & 1)] = 0;
+        }
+    }
+    const int waves = blockDim.x >> 6, l = lane_id();
+    for (int p = blockIdx.x * waves + wave_id(); p < nF; p += gridDim.x * waves) {
+        const int node = F[p];
+        const int r = root[node];
+        if (l == 0) {
+            const int qpos = comp_base[r] + done_cur[r] + (p - seg_start_cur[r]);
+            scratch_node[qpos] = node;
+            scratch_seed[qpos] = r;
+        }
+        const int st = start_len[node * 2], ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);  // canonical lists: <= 1000
+        const int lab = thr.mode == 0 ? (int)sem[node] : 0;
+        unsigned long long *am = amask + mask_slot(st, node);
+        // four 64-edge slices per trip: the four index loads, then the four claim gathers are in flight together
+        for (int t0 = 0; t0 < ln; t0 += 256) {
+            int j[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u + l;
+                j[u] = t < ln ? ball_idx[st + t] : -1;
+            }
+            int sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = j[u] >= 0 ? claim[j[u]] : -1;
+                // the label gather rides along with the claim gather (one round trip instead of two in a row; the chain
+                // index -> claim -> label -> coherent re-read -> atomic bounds this kernel, not the request rate)
+                sj[u] = (thr.mode == 0 && j[u] >= 0) ? (int)sem[j[u]] : lab;
+                if (GROUPS && j[u] >= 0 && root[j[u]] != r) sj[u] = lab + 1;   // other group: never label-compatible
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t0 + 64 * u >= ln) break;
+                // stale reads are only ever too large -> a redundant atomic
+                bool post = c[u] > p && sj[u] == lab;
+                // the L2 of an XCD does not see the atomics of the other seven: a cached line keeps saying "unclaimed"
+                // long after the node was taken, and every such edge would post an atomic (memory-side, expensive);
+                // a coherent re-read filters them
+                if (post) post = ld_agent(&claim[j[u]]) > p;
+                if (post) atomicMin(&claim[j[u]], p);
+                const unsigned long long m = __ballot(post);
+                if (l == 0) am[(t0 >> 6) + u] = m;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dir_win_kernel(int level, const int *__restrict__ ball_idx,
+                                                       const int *__restrict__ start_len,
+                                                       const int *__restrict__ root, const int *__restrict__ F,
+                                                       int *counters, int *claim,
+                                                       const unsigned long long *__restrict__ amask,
+                                                       unsigned long long *tile_status, int *F_next, int *seg_start_next,
+                                                       int *seg_cnt_next)
+{
+    __shared__ unsigned long long s_wm[DIR_TILE][MAX_SLICES];
+    __shared__ int s_cnt[DIR_TILE];
+    __shared__ int s_off[DIR_TILE];
+    __shared__ int s_bcast[2];
+    __shared__ int s_node[DIR_TILE], s_st[DIR_TILE], s_ln[DIR_TILE];
+    const int nF = counters[6 + (level & 1)];
+    const int ntiles = (nF + DIR_TILE - 1) / DIR_TILE;
+    const int l = lane_id(), wv = wave_id();
+    constexpr int PER_WAVE = DIR_TILE / 4;
+    constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INCL = 2ull << 62, VAL = (1ull << 62) - 1;
+    if ((int)blockIdx.x >= ntiles) return;  // surplus workgroups leave without touching the ticket counter
+    for (;;) {
+        if (threadIdx.x == 0) s_bcast[0] = atomicAdd(&counters[8], 1);
+        __syncthreads();
+        const int tile = s_bcast[0];
+        if (tile >= ntiles) break;
+        if (threadIdx.x < DIR_TILE) {   // the tile's list headers, all positions at once
+            const int pos = tile * DIR_TILE + threadIdx.x;
+            int node = 0, st = 0, ln = 0;
+            if (pos < nF) {
+                node = F[pos];
+                st = start_len[node * 2];
+                ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);
+            }
+            s_node[threadIdx.x] = node; s_st[threadIdx.x] = st; s_ln[threadIdx.x] = ln;
+        }
+        __syncthreads();
+        // ---- pass 1: winners per position, masks kept in LDS
+        for (int k = 0; k < PER_WAVE; k++) {
+            const int q = wv * PER_WAVE + k, pos = tile * DIR_TILE + q;
+            int count = 0;
+            if (pos < nF) {
+                const int node = s_node[q];
+                const int st = s_st[q], ln = s_ln[q];
+                const unsigned long long *am = amask + mask_slot(st, node);
+                const int nsl = (ln + 63) >> 6;
+                const unsigned long long mine = l < nsl ? am[l] : 0ull;   // all slice masks of the list in one load
+                for (int c0 = 0; c0 < nsl; c0 += 4) {   // four slices in flight: index gathers, then claim gathers
+                    int j[4], cl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const unsigned long long m = __shfl(mine, (c0 + u) & 63, 64);
+                        j[u] = (c0 + u < nsl && ((m >> l) & 1ull)) ? ball_idx[st + 64 * (c0 + u) + l] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cl[u] = j[u] >= 0 ? claim[j[u]] : -2;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (c0 + u >= nsl) break;
+                        const unsigned long long wm = __ballot(cl[u] == pos);
+                        if (l == 0) s_wm[q][c0 + u] = wm;
+                        count += __popcll(wm);
+                    }
+                }
+            }
+            if (l == 0) s_cnt[q] = count;
+        }
+        __syncthreads();
+        // ---- tile scan + decoupled look-back over the preceding tiles
+        if (wv == 0) {
+            const int v = l < DIR_TILE ? s_cnt[l] : 0;
+            const int incl = wave_incl_scan(v);
+            if (l < DIR_TILE) s_off[l] = incl - v;
+            const int total = __shfl(incl, 63, 64);
+            // relaxed on purpose: the word carries its own payload, nothing else is ordered by it (an acquire / release
+            // pair at agent scope invalidates / writes back the L2 on every poll: a 10x slower kernel)
+            if (l == 0)
+                __hip_atomic_store(&tile_status[tile], (tile == 0 ? FLAG_INCL : FLAG_AGG) | (unsigned long long)total,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look-back, 64 predecessors per step: sum the aggregates down to the nearest tile whose inclusive prefix
+            // is known (tile -1 counts as "inclusive 0")
+            int base = 0;
+            for (int hi = tile - 1; hi >= 0;) {
+                const int t = hi - l;
+                const unsigned long long sv = t >= 0 ? __hip_atomic_load(&tile_status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                     : FLAG_INCL;
+                const unsigned long long incl_m = __ballot((sv >> 62) == 2ull), inval_m = __ballot((sv >> 62) == 0ull);
+                const int first = incl_m ? __ffsll((long long)incl_m) - 1 : 64;
+                const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                if (inval_m & need) continue;  // a predecessor in the window has not published yet: poll again
+                base += wave_sum(l <= first ? (int)(sv & VAL) : 0);
+                if (first < 64) break;
+                hi -= 64;
+            }
+            if (l == 0) {
+                if (tile > 0)
+                    __hip_atomic_store(&tile_status[tile], FLAG_INCL | (unsigned long long)(base + total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_bcast[1] = base;
+                if (tile == ntiles - 1) counters[6 + ((level + 1) & 1)] = base + total;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: winners out, in (position, slot) order
+        const int base = s_bcast[1];
+        for (int k = 0; k < PER_WAVE; k++) {
+            const int q = wv * PER_WAVE + k, pos = tile * DIR_TILE + q;
+            const int total = s_cnt[q];
+            if (pos >= nF || total == 0) continue;
+            const int node = s_node[q];
+            const int st = s_st[q], ln = s_ln[q];
+            const int nsl = (ln + 63) >> 6;
+            int out = base + s_off[q];
+            if (l == 0) {
+                const int r = root[node];
+                atomicMin(&seg_start_next[r], out);
+                atomicAdd(&seg_cnt_next[r], total);
+            }
+            for (int c = 0; c < nsl; c++) {
+                const unsigned long long wm = s_wm[q][c];
+                if (wm == 0ull) continue;
+                if ((wm >> l) & 1ull) {
+                    const int j = ball_idx[st + 64 * c + l];
+                    F_next[out + __popcll(wm & ((1ull << l) - 1ull))] = j;
+                    claim[j] = -1;  // visited
+                }
+                out += __popcll(wm);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// cluster of a seed = what the expansion reached; counters[9] counts the seeds whose group holds more than that
+// (stage 1: the component has leftovers; stage 2: impossible, checked)
+__global__ void dir_finish_kernel(const int *__restrict__ worklist, int *counters, const int *__restrict__ comp_size,
+                                  const int *__restrict__ comp_base, const int *__restrict__ done,
+                                  const int *__restrict__ seg_cnt, int *cl_size, int *cl_start, int *defi)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= counters[0]) return;
+    const int r = worklist[w];
+    const int reached = done[r] + seg_cnt[r];
+    cl_size[r] = reached;
+    cl_start[r] = comp_base[r];
+    const int short_of = reached != comp_size[r];
+    defi[r] = short_of;  // (not final while the frontier is alive: the host looks at counters[9] only once it is empty)
+    if (short_of) atomicAdd(&counters[9], 1);
+}
+
+// ---- stage 2
+// leftovers = unvisited points of the components stage 1 did not exhaust: own label, queued in left[] (counters[10])
+__global__ void dir2_collect_kernel(int N, const int *__restrict__ root, const int *__restrict__ defi,
+                                    const int *__restrict__ claim, int *lab, int *comp_size, int *left, int *counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool is_left = defi[root[i]] && claim[i] == INT_BIG;
+    lab[i] = is_left ? i : -1;
+    if (is_left) comp_size[i] = 0;
+    const unsigned long long m = __ballot(is_left);
+    if (m) {
+        int base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane_id() == leader) base = atomicAdd(&counters[10], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (is_left) left[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+    }
+}
+
+// one round of min-propagation: every leftover pushes its label along its out-edges to leftovers with a larger one;
+// counters[11 + (round & 1)] says whether anything moved (the other one is cleared for the next round)
+__global__ __launch_bounds__(256) void dir2_propagate_kernel(Thr thr, int round, const int16_t *__restrict__ sem,
+                                                              const int *__restrict__ ball_idx,
+                                                              const int *__restrict__ start_len,
+                                                              const int *__restrict__ left, int *lab, int *counters)
+{
+    const int nleft = counters[10];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[11 + ((round + 1) & 1)] = 0;
+    const int waves = blockDim.x >> 6, l = lane_id();
+    bool moved = false;
+    for (int q = blockIdx.x * waves + wave_id(); q < nleft; q += gridDim.x * waves) {
+        const int v = left[q];
+        const int lv = ld_agent(&lab[v]);
+        const int st = start_len[v * 2], ln = start_len[v * 2 + 1];
+        const int sv = thr.mode == 0 ? (int)sem[v] : 0;
+        for (int t = l; t < ln; t += 64) {
+            const int u = ball_idx[st + t];
+            if (thr.mode == 0 && (int)sem[u] != sv) continue;
+            // a stale (cached) label is only ever too large: a redundant atomic at worst; visited points carry -1
+            if (lab[u] > lv && atomicMin(&lab[u], lv) > lv) moved = true;
+        }
+    }
+    if (__ballot(moved) && l == 0) counters[11 + (round & 1)] = 1;
+}
+
+// the labels become the groups: root[] rewritten for the leftovers, group sizes counted at the label
+__global__ void dir2_count_kernel(const int *__restrict__ left, const int *lab, int *root, int *comp_size,
+                                  int *counters)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) counters[0] = 0;  // the work list is rebuilt by the select kernel that follows
+    if (q >= counters[10]) return;
+    const int v = left[q];
+    const int a = ld_agent(&lab[v]);
+    root[v] = a;
+    atomicAdd(&comp_size[a], 1);
+}
+
+__global__ void dir2_select_kernel(Thr thr, const int *__restrict__ left, const int *__restrict__ root,
+                                   const int *__restrict__ comp_size, int *worklist, int *counters)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= counters[10]) return;
+    const int v = left[q];
+    if (root[v] == v && qualifies(thr, comp_size[v], v)) worklist[atomicAdd(&counters[0], 1)] = v;
+}
+
 // one cluster per qualifying component: seed = root, size = component size, members at comp_base
 __global__ void glob_finish_kernel(const int *__restrict__ worklist, const int *__restrict__ counters,
                                    const int *__restrict__ comp_size, const int *__restrict__ comp_base, int *cl_size,
@@ -775,8 +1109,8 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
 
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
-        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2];
-    unsigned long long *vp, *cc, *tile_status;
+        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2], *defi, *left;
+    unsigned long long *vp, *cc, *tile_status, *amask;
     int *cand, *cnt;
     void *scan_ws;
 };
@@ -790,7 +1124,8 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     };
     const size_t nb = sizeof(int) * (size_t)N;
     w.parent = take(nb); w.root = take(nb); w.comp_size = take(nb); w.visited = take(nb); w.claim = take(nb); w.worklist = take(nb);
-    w.scratch_node = take(nb); w.scratch_seed = take(nb); w.cl_size = take(nb); w.cl_start = take(nb);
+    w.scratch_node = take(2 * nb); w.scratch_seed = take(2 * nb); w.cl_size = take(nb); w.cl_start = take(nb);
+    w.defi = take(nb); w.left = take(nb);
     w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
     // chip-wide expansion: frontier double buffer, per-component bookkeeping double-buffered by level parity, one
     // node words / candidate tags / claims / child counts, scan state per tile of 64 positions
@@ -800,7 +1135,8 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.vp = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N);
     w.cc = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N);
     w.cand = take(nb); w.cnt = take(nb);
-    w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / WIN_TILE + 2));
+    w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / DIR_TILE + 2));
+    w.amask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N * (MAX_SLICES + 1));
     w.counters = take(sizeof(int) * 16);
     w.scan_ws = take(ms3d_scan_workspace_bytes());
     return off;
@@ -826,24 +1162,32 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     BfsWorkspace w;
     if (carve(w, N, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
     const int nb = ms3d_divup(N, 256);
-    bfs_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent, w.comp_size, w.visited, w.claim,
-                                           w.cl_size, w.scratch_seed, w.counters);
-    MS3D_LAUNCH_CHECK();
-    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
-    MS3D_LAUNCH_CHECK();
-    bfs_link_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
-    MS3D_LAUNCH_CHECK();
-    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
-    MS3D_LAUNCH_CHECK();
-    bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx, start_len,
-                                                                         w.parent);
-    MS3D_LAUNCH_CHECK();
-    bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
-    MS3D_LAUNCH_CHECK();
-    bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
-    MS3D_LAUNCH_CHECK();
-    bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
-    MS3D_LAUNCH_CHECK();
+    // weak components, their sizes, and the work list of the components that can hold a qualifying cluster
+    auto prepare = [&]() -> int {
+        bfs_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent, w.comp_size, w.visited, w.claim,
+                                               w.cl_size, w.scratch_seed, w.defi, w.counters);
+        MS3D_LAUNCH_CHECK();
+        bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_link_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_hook_kernel<<<min(ms3d_divup(N, 4), 256 * 32), 256, 0, stream>>>(N, thr, capped_hint == 0 ? 1 : 0, sem, ball_idx,
+                                                                             start_len, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_compress_kernel<<<nb, 256, 0, stream>>>(N, w.parent);
+        MS3D_LAUNCH_CHECK();
+        bfs_flatten_kernel<<<nb, 256, 0, stream>>>(N, w.parent, w.root, w.comp_size, start_len, w.counters);
+        MS3D_LAUNCH_CHECK();
+        bfs_select_kernel<<<nb, 256, 0, stream>>>(N, thr, w.root, w.comp_size, w.worklist, w.counters);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    };
+    {
+        const int rc0 = prepare();
+        if (rc0) return rc0;
+    }
     // Dense symmetric graphs (shifted coordinates: hundreds of neighbours per point, a handful of BFS levels)
     // are expanded by the whole chip level by level; sparse or capped (directed) graphs by the replay kernel.
     // When the ball query already told us that no list was capped (capped_hint == 0) nothing has to be read back
@@ -855,13 +1199,25 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         fprintf(stderr, "[bfs] %s N=%d edges=%ld mode=%d hint=%d err=%d\n", tag, N, n_edges, thr.mode, capped_hint, (int)e_); \
     }
     DBG("after select");
-    bool replay = true, dense = false;
+    bool replay = true, dense = false, directed = false, stage2 = false;
     const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
     int level = 0;
     auto run_levels = [&](int nlev) -> int {
         for (int it = 0; it < nlev; it++, level++) {
             const int c = level & 1, n = c ^ 1;
             int *Fc = c ? w.Fb : w.Fa, *Fn = c ? w.Fa : w.Fb;
+            if (directed) {
+                auto claim_fn = stage2 ? dir_claim_kernel<true> : dir_claim_kernel<false>;
+                claim_fn<<<256 * 8, 256, 0, stream>>>(thr, level, sem, ball_idx, start_len, w.root, Fc, w.counters,
+                                                             w.worklist, w.comp_base, w.done[c], w.done[n], w.seg_start[c],
+                                                             w.seg_start[n], w.seg_cnt[c], w.seg_cnt[n], w.claim,
+                                                             w.scratch_node, w.scratch_seed, w.amask, w.tile_status);
+                MS3D_LAUNCH_CHECK();
+                dir_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.claim, w.amask,
+                                                           w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n]);
+                MS3D_LAUNCH_CHECK();
+                continue;
+            }
             glob_mark_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.worklist,
                                                          w.comp_base, w.done[c], w.done[n], w.seg_start[c], w.seg_start[n],
                                                          w.seg_cnt[c], w.seg_cnt[n], w.vp, w.cand, w.cnt, w.scratch_node,
@@ -875,6 +1231,19 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         }
         return 0;
     };
+    auto launch_replay = [&]() -> int {
+        if (n_edges >= (long)N * 24)
+            bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        else
+            bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
+                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
+                                                              w.scratch_seed, w.cl_size, w.cl_start);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    };
+    static const bool dir_on = [] { const char *e = getenv("MS3D_BFS_DIRECTED"); return !e || atoi(e) != 0; }();
     if (n_edges >= (long)N * 24) {
         int capped = capped_hint;
         if (capped < 0) {
@@ -892,18 +1261,17 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                                                          w.seg_start[0], w.seg_cnt[0], w.vp);
             MS3D_LAUNCH_CHECK();
             DBG("after glob_init");
+        } else if (dir_on) {
+            replay = false;
+            directed = true;
+            dir_init_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done[0],
+                                                        w.seg_start[0], w.seg_cnt[0], w.claim);
+            MS3D_LAUNCH_CHECK();
         }
     }
     if (replay) {
-        if (n_edges >= (long)N * 24)
-            bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
-                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
-        else
-            bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
-                                                              w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
-        MS3D_LAUNCH_CHECK();
+        const int rc2 = launch_replay();
+        if (rc2) return rc2;
     }
     int host[16];
     for (;;) {
@@ -919,20 +1287,62 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                                                            w.cl_start);
             MS3D_LAUNCH_CHECK();
         }
+        if (directed) {
+            int rc2 = run_levels(8);   // a capped list spans its blob: 2-4 levels
+            if (rc2) return rc2;
+            MS3D_CHECK(hipMemsetAsync(w.counters + 9, 0, sizeof(int), stream));
+            dir_finish_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.comp_size, w.comp_base, w.done[level & 1],
+                                                          w.seg_cnt[level & 1], w.cl_size, w.cl_start, w.defi);
+            MS3D_LAUNCH_CHECK();
+        }
         bfs_keep_kernel<<<nb, 256, 0, stream>>>(N, thr, w.cl_size, w.keep, w.keep_size);
         MS3D_LAUNCH_CHECK();
         int rc = ms3d_exclusive_scan_i32(w.keep, w.cid, N, w.counters + 3, w.scan_ws, stream);
         if (rc) return rc;
         rc = ms3d_exclusive_scan_i32(w.keep_size, w.out_off, N, w.counters + 4, w.scan_ws, stream);
         if (rc) return rc;
-        bfs_emit_kernel<<<nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
+        bfs_emit_kernel<<<2 * nb, 256, 0, stream>>>(N, w.counters, w.scratch_node, w.scratch_seed, w.cl_size, w.cl_start, w.cid,
                                                w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
         MS3D_LAUNCH_CHECK();
         DBG("after emit");
         MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
         MS3D_CHECK(hipStreamSynchronize(stream));
-        if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], level);
-        if (!dense || host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
+        if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d | %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8], host[9], level);
+        if (dense) {
+            if (host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
+            continue;
+        }
+        if (directed) {
+            if (host[6 + (level & 1)] != 0) continue;     // deeper than the levels launched so far
+            if (host[9] == 0) break;                      // every group was exhausted by its seed: done
+            if (stage2) return MS3D_E_INTERNAL;           // a label group its own seed does not reach: cannot happen
+            // stage 2: the leftovers of the components that hold more than the cluster of their root
+            stage2 = true;
+            int *lab = w.visited;
+            dir2_collect_kernel<<<nb, 256, 0, stream>>>(N, w.root, w.defi, w.claim, lab, w.comp_size, w.left, w.counters);
+            MS3D_LAUNCH_CHECK();
+            for (int round = 0;;) {
+                for (int k = 0; k < 4; k++, round++) {
+                    dir2_propagate_kernel<<<256 * 4, 256, 0, stream>>>(thr, round, sem, ball_idx, start_len, w.left, lab,
+                                                                      w.counters);
+                    MS3D_LAUNCH_CHECK();
+                }
+                MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
+                MS3D_CHECK(hipStreamSynchronize(stream));
+                if (host[11 + ((round - 1) & 1)] == 0) break;   // the last round moved nothing: fixed point
+            }
+            const int left_grid = ms3d_divup(host[10] > 0 ? host[10] : 1, 256);
+            dir2_count_kernel<<<left_grid, 256, 0, stream>>>(w.left, lab, w.root, w.comp_size, w.counters);
+            MS3D_LAUNCH_CHECK();
+            dir2_select_kernel<<<left_grid, 256, 0, stream>>>(thr, w.left, w.root, w.comp_size, w.worklist, w.counters);
+            MS3D_LAUNCH_CHECK();
+            level = 0;
+            dir_init_kernel<<<left_grid, 256, 0, stream>>>(w.worklist, w.comp_size, w.counters, w.Fa, w.comp_base, w.done[0],
+                                                          w.seg_start[0], w.seg_cnt[0], w.claim);
+            MS3D_LAUNCH_CHECK();
+            continue;
+        }
+        break;
     }
     counts[0] = host[3];
     counts[1] = host[4];

@@ -372,3 +372,44 @@ def test_bfs_dense_graph_with_many_levels(be, oracle):
         a, o = be.pg_bfs_cluster(dev(sem), graph[0], graph[1], 50)
         assert np.array_equal(o.cpu().numpy(), want[1]) and o.numel() - 1 == 2
         assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_bfs_directed_graph_leftover_clusters(be, oracle, seed):
+    """a synthetic DIRECTED dense graph (one list at the 1000-entry cap switches the directed path on): in every block
+    the low points form the cluster of the block's first point, the high points are in nobody's list from below and
+    form further clusters among themselves whose seeds the serial order decides (chains, merges, singletons) -- stage 2
+    of the chip-wide expansion (smallest-ancestor labels) must reproduce them, with and without semantic labels"""
+    rng = np.random.default_rng(100 + seed)
+    blocks, low, high = 24, 220, 90
+    per = low + high
+    n = blocks * per + 1000
+    lists = []
+    for bk in range(blocks):
+        base = bk * per
+        for i in range(per):
+            tgt = set((base + rng.choice(low, 40, replace=False)).tolist())
+            if i >= low:                                     # a high point: a few edges to other high points
+                tgt |= set((base + low + rng.choice(high, rng.integers(0, 3), replace=False)).tolist())
+            tgt.add(base + i)
+            lists.append(np.array(sorted(tgt), np.int32))
+    tail = blocks * per                                      # 1000 points that all list each other: capped lists
+    for i in range(1000):
+        lists.append(np.arange(tail, tail + 1000, dtype=np.int32))
+    sl = np.zeros((n, 2), np.int32)
+    sl[:, 1] = [len(x) for x in lists]
+    sl[1:, 0] = np.cumsum(sl[:-1, 1])
+    idx = np.concatenate(lists)
+    assert idx.size >= 24 * n and sl[:, 1].max() == 1000
+    sem = np.full(n, 2, np.int16)
+    sem[rng.random(n) < 0.05] = 5                            # a second class cuts some of the edges
+    want = oracle.pg_bfs_cluster(sem, idx, sl, 2)
+    assert want[1].size - 1 > 3 * blocks                     # many leftover clusters of two and more points
+    a, o = be.pg_bfs_cluster(dev(sem), dev(idx), dev(sl), 2)
+    assert np.array_equal(o.cpu().numpy(), want[1])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    mean = [10.0, 10.0, 10.0, 10.0, 10.0]
+    want = oracle.sg_bfs_cluster(mean, idx, sl, 0.25, 1)     # size > 2.5
+    a, o = be.sg_bfs_cluster(mean, dev(idx), dev(sl), 0.25, 1)
+    assert np.array_equal(o.cpu().numpy(), want[1])
+    assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
