@@ -15,9 +15,10 @@ The object describes the dominant kernel family of the step -- ALL sparse-convol
 backward-data, backward-weight: the SURVEY 8d / BASELINE.md figure, sum over the layers of
 nM*(Cin+Cout)*4 + nM*8 + K*Cin*Cout*4 with each table's real pair count nM, divided by the summed kernel time) --
 and `top_kernels` lists the five largest kernel groups by time (convolutions by variant and shape, and the grouping
-operators with their SURVEY 8d byte formulas).  `traffic` (HBM bytes from PMC counters) needs separate rocprofv3
---pmc passes and is therefore not produced by this script: the per-kernel FETCH_SIZE / WRITE_SIZE tables of the
-same command are committed under profiles/ and discussed in DESIGN.md.
+operators with their SURVEY 8d byte formulas).  `traffic` (HBM bytes of the same convolution kernels per step, from
+PMC counters) needs separate rocprofv3 --pmc passes, which this script cannot run on itself: it is read from
+profiles/r02_traffic_<model>.json (made by tools/scripts/pmc_traffic.sh from FETCH_SIZE / WRITE_SIZE passes of this
+script at the commit named there; corrections as MI355X_MICROARCH.md prescribes) and is null when that file is absent.
 
 `cpu_baseline` times the same training step on the host cores with every operator served by the CPU oracle (a PORT
 of the reference algorithms -- the reference's own CPU path needs MinkowskiEngine, which is not available), on a
@@ -172,7 +173,7 @@ def _conv_variant(kind, K, cin, cout, rows, lib):
     return "pair-list" if listed and max(cin, cout) <= 32 else "table-walk"
 
 
-def roofline_report(groups, n_sampled, lib):
+def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     """groups: KernelTimer.summary() over `n_sampled` steps -> (roofline dict, top_kernels list)"""
     if not groups or n_sampled == 0:
         return None, None
@@ -180,7 +181,7 @@ def roofline_report(groups, n_sampled, lib):
     tot = {f: sum(v[f] for v in conv.values()) for f in ("ms", "bytes", "flops", "launches")}
     ach = tot["bytes"] / (tot["ms"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
             "kernel": "spconv_* -- every sparse-convolution launch of the step (forward, backward-data, backward-weight; "
                       "backbone + ScoreNet): sum of algorithmic bytes / sum of kernel time (SURVEY 8d)",
             "launches_per_step": round(tot["launches"] / n_sampled, 1),
@@ -189,6 +190,15 @@ def roofline_report(groups, n_sampled, lib):
             "flops_per_step": int(tot["flops"] / n_sampled),
             "mfma_f32_frac": round(tot["flops"] / (tot["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
             "steps_sampled": n_sampled}
+    # HBM bytes of the same kernels from the PMC passes committed with this code (separate rocprofv3 --pmc FETCH_SIZE /
+    # --pmc WRITE_SIZE runs of this script, tools/scripts/pmc_traffic.sh); null when the file is missing or is for
+    # another model
+    tfile = os.path.join(ROOT, "profiles", f"r02_traffic_{model_name}.json")
+    if os.path.exists(tfile):
+        with open(tfile) as fh:
+            t = json.load(fh)
+        roof["traffic"] = t.get("spconv_hbm_bytes_per_step")
+        roof["traffic_source"] = f"profiles/{os.path.basename(tfile)} ({t.get('commit', '?')}): {t.get('method', '')}"
     rows = []
     for k, v in groups.items():
         if k[0].startswith("spconv_"):
@@ -203,7 +213,17 @@ def roofline_report(groups, n_sampled, lib):
                      "algorithmic_bytes_per_step": int(v["bytes"] / n_sampled), "GB/s": round(gbs, 1),
                      "frac": round(gbs / HBM_PEAK_GBS, 4)})
     rows.sort(key=lambda r: -r["ms_per_step"])
-    return roof, rows[:5]
+    spans = [r for r in rows if r["name"].startswith("grouping span")]
+    rows = [r for r in rows if not r["name"].startswith("grouping span")]
+    for r in rows:
+        if r["name"] in ("pg_bfs_cluster", "ballquery_batch_p") and spans:
+            r["note"] = ("two calls per step (original and shifted coordinates) run CONCURRENTLY on two streams: "
+                         "ms_per_step adds their intervals; the wall time of all four calls together is the span below")
+    top = rows[:5]
+    for r in spans:
+        r.pop("GB/s", None); r.pop("frac", None); r.pop("algorithmic_bytes_per_step", None)
+        top.append(r)
+    return roof, top
 
 
 def main():
@@ -288,7 +308,7 @@ def main():
             timer.sampling = False
             be.kernel_timer = None
             groups = timer.summary()
-            roof, top = roofline_report(groups, n_sampled, be.lib)
+            roof, top = roofline_report(groups, n_sampled, be.lib, args.model)
             if roof:
                 line["roofline"], line["top_kernels"] = roof, top
             if args.all_kernels:

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
-from ..backend import side_stream as _side_stream, worker as _worker
+from ..backend import get_backend, side_stream as _side_stream, worker as _worker
 from ..common_ops.functions import common_ops, pointgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
@@ -62,6 +62,8 @@ class PointGroup(GeneralModel):
             # other's host round trips (the library calls release the GIL; scratch buffers are per stream).
             main = torch.cuda.current_stream()
             side = _side_stream(xyz.device)
+            timer = getattr(get_backend(), "kernel_timer", None)   # bench.py: wall span of the two concurrent groupings
+            span0 = timer.op_begin() if timer is not None else None
             side.wait_stream(main)
 
             def second():
@@ -75,6 +77,8 @@ class PointGroup(GeneralModel):
             finally:
                 p_orig, o_orig = pending.result()
                 main.wait_stream(side)
+            if span0 is not None:
+                timer.op_end("grouping span (both ball queries + both BFS, two streams, one interval)", span0, 0)
             p_orig.record_stream(main)
             o_orig.record_stream(main)
         else:

@@ -1,11 +1,20 @@
-"""Host clock vs GPU clock per phase of a training step: where the GPU waits for Python (host-bound phases) and where
-Python waits for the GPU.  usage: python tools/phase_timeline.py"""
-import sys, os, time, torch
+"""Host clock vs GPU clock per phase of a training step, in bench.py's pipelined loop (no sync between steps, next
+batch's coordinate work prefetched): per phase the host time, the GPU time between the phase's boundary events, and the
+GPU's LAG behind the host at the phase's end (lag ~ 0: the GPU ran dry and waits for Python there; lag of milliseconds:
+the host is ahead and the phase is GPU-bound).
+usage: python tools/phase_timeline.py [--model pointgroup|hais|softgroup] [--steps N]"""
+import sys, os, time, argparse, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
-from minsu3d_amd.config import load_config
+import minsu3d_amd.MinkowskiEngine as ME
 
-cfg = load_config(); dev = torch.device("cuda", 0)
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="pointgroup")
+ap.add_argument("--steps", type=int, default=12)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+from minsu3d_amd.config import load_config
+cfg = load_config([f"model={args.model}", "data=scannetv2"])
 model = bench.build(cfg, dev); opt = model.configure_optimizers()
 batches = [bench.make_batch([4 * i + j for j in range(4)], dev) for i in range(3)]
 marks = []
@@ -22,32 +31,39 @@ model.score_net.register_forward_pre_hook(lambda m, a: mark("grouping_end/scoren
 model.score_net.register_forward_hook(lambda m, a, o: mark("scorenet_end"))
 
 
-def step(b):
+def step(b, nxt):
     mark("step_begin")
     opt.zero_grad(set_to_none=True)
     out = model(b)
     mark("forward_end")
     loss = sum(model._loss(b, out).values())
     mark("loss_end")
+    ME.prefetch_coordinates(nxt["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
+                            channels=model.backbone.level_channels)
     loss.backward()
     mark("backward_end")
     opt.step()
     mark("opt_end")
 
 
-for i in range(5): step(batches[i % 3])
+for i in range(5): step(batches[i % 3], batches[(i + 1) % 3])
 torch.cuda.synchronize()
-acc = {}
-N = 12
+marks.clear()
+ref = torch.cuda.Event(enable_timing=True); ref.record(); torch.cuda.synchronize()
+ref_host = time.perf_counter()
+N = args.steps
 for i in range(N):
-    marks.clear()
-    step(batches[i % 3])
-    torch.cuda.synchronize()
-    for (n0, h0, e0), (n1, h1, e1) in zip(marks[:-1], marks[1:]):
-        a = acc.setdefault(f"{n0} -> {n1}", [0.0, 0.0])
-        a[0] += (h1 - h0) * 1e3; a[1] += e0.elapsed_time(e1)
-print(f"{'phase':55s} {'host ms':>8s} {'gpu ms':>8s}")
+    step(batches[(i + 5) % 3], batches[(i + 6) % 3])
+mark("end")
+torch.cuda.synchronize()
+wall = (time.perf_counter() - ref_host) * 1e3
+acc = {}
+for (n0, h0, e0), (n1, h1, e1) in zip(marks[:-1], marks[1:]):
+    a = acc.setdefault(f"{n0} -> {n1}", [0.0, 0.0, 0.0, 0])
+    a[0] += (h1 - h0) * 1e3; a[1] += e0.elapsed_time(e1)
+    a[2] += ref.elapsed_time(e1) - (h1 - ref_host) * 1e3; a[3] += 1
+print(f"{'phase':55s} {'host ms':>8s} {'gpu ms':>8s} {'lag at end':>11s}")
 th = tg = 0
-for k, (h, g) in acc.items():
-    print(f"{k:55s} {h / N:8.2f} {g / N:8.2f}"); th += h / N; tg += g / N
-print(f"{'total':55s} {th:8.2f} {tg:8.2f}")
+for k, (h, g, lag, n) in acc.items():
+    print(f"{k:55s} {h / N:8.2f} {g / N:8.2f} {lag / n:11.2f}"); th += h / N; tg += g / N
+print(f"{'total':55s} {th:8.2f} {tg:8.2f}    wall/step {wall / N:.2f}")
