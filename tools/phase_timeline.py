@@ -27,8 +27,10 @@ def mark(name):
 
 model.backbone.register_forward_pre_hook(lambda m, a: mark("backbone_begin"))
 model.backbone.register_forward_hook(lambda m, a, o: mark("backbone_end"))
-model.score_net.register_forward_pre_hook(lambda m, a: mark("grouping_end/scorenet_begin"))
-model.score_net.register_forward_hook(lambda m, a, o: mark("scorenet_end"))
+score = getattr(model, "score_net", None) or getattr(model, "tiny_unet", None)
+if score is not None:
+    score.register_forward_pre_hook(lambda m, a: mark("grouping_end/scorenet_begin"))
+    score.register_forward_hook(lambda m, a, o: mark("scorenet_end"))
 
 
 def step(b, nxt):
