@@ -100,6 +100,17 @@ int ms3d_sec_mean(int nProposal, int C, const float *inp, const int *offsets, fl
 int ms3d_sec_min(int nProposal, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream);
 int ms3d_sec_max(int nProposal, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream);
 
+/* ---- proposal voxelisation: the arithmetic of clusters_voxelization (minsu3d/model/general_model.py:152-193) between
+ * the proposal lists and sparse_quantize -- gather the member coordinates, centre them on the proposal mean
+ * (sec_mean's serial order), per-proposal scale = clamp(1 / max_c((hi - lo) / spatial_shape) - 0.01, max = scale),
+ * random placement inside the cube with the two U(0,1)^3 draws rand6 = (u1, u2) (device memory), truncate.
+ * clusters_idx [S,2] int64 (proposal, point) grouped by proposal; offsets [P+1]; out [S,4] int32 (proposal, x, y, z).
+ * Every float operation is the correctly rounded f32 operation of the reference's torch expression, in its order.
+ * workspaces: xyz_ws 3*S, mean_ws 3*P, param_ws 4*P floats. */
+int ms3d_proposal_voxel_coords(const long long *clusters_idx, int S, const int *offsets, int P, const float *coords,
+                               float scale, int spatial_shape, const float *rand6, float *xyz_ws, float *mean_ws,
+                               float *param_ws, int *out, ms3d_stream_t stream);
+
 /* ---- pools: replace roipool_fp_cuda / roipool_bp_cuda / global_avg_pool_fp_cuda / _bp_cuda,
  * roipool/roipool.h:17-37 (kernels roipool.cu:12-108).  argmax = first maximum (strict >). */
 int ms3d_roipool_fp(int nProposal, int C, const float *feats, const int *proposals_offset, float *output_feats,

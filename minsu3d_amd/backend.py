@@ -249,6 +249,23 @@ class HipBackend:
     def sec_max(self, inp, offsets): return self._seg("ms3d_sec_max", inp, offsets)
     def global_avg_pool_fp(self, feats, offsets): return self._seg("ms3d_global_avg_pool_fp", feats, offsets)
 
+    def proposal_voxel_coords(self, clusters_idx, clusters_offset, coords, scale, spatial_shape, rand6):
+        """(proposal, x, y, z) i32 [S, 4]: member coordinates centred on the proposal mean, scaled into the
+        `spatial_shape` cube and randomly placed in it (the arithmetic of the reference's clusters_voxelization,
+        general_model.py:152-193, in its float operation order); rand6 = the two U(0,1)^3 draws (u1, u2) on the device"""
+        ci = self._dev(clusters_idx); off = self._dev(clusters_offset); xyz = self._dev(coords); r6 = self._dev(rand6)
+        assert ci.dtype == torch.int64 and ci.is_contiguous() and off.dtype == torch.int32
+        assert xyz.dtype == torch.float32 and xyz.is_contiguous() and r6.dtype == torch.float32 and r6.numel() == 6
+        S, P, dev = ci.size(0), off.numel() - 1, xyz.device
+        out = torch.empty((S, 4), dtype=torch.int32, device=dev)
+        ws = torch.empty(3 * S + 7 * max(P, 1), dtype=torch.float32, device=dev)
+        base = ws.data_ptr()
+        _lib.check(self.lib.ms3d_proposal_voxel_coords(
+            _lib.ptr(ci), S, _lib.ptr(off), P, _lib.ptr(xyz), C.c_float(float(scale)), int(spatial_shape), _lib.ptr(r6),
+            C.c_void_p(base), C.c_void_p(base + 12 * S), C.c_void_p(base + 12 * S + 12 * max(P, 1)), _lib.ptr(out),
+            _lib.stream_handle()), "ms3d_proposal_voxel_coords")
+        return out
+
     def roipool_fp(self, feats, offsets):
         feats = self._dev(feats); offsets = self._dev(offsets)
         P, Cc = offsets.numel() - 1, feats.size(1)

@@ -47,6 +47,18 @@ __device__ __forceinline__ int wave_min(int v)
     for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
     return v;
 }
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
 // number of set bits of a wave ballot below this lane
 __device__ __forceinline__ int ballot_rank(unsigned long long m)
 {

@@ -233,6 +233,98 @@ __global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, float *_
     }
 }
 
+// ---- proposal voxelisation (the arithmetic of the reference's clusters_voxelization, general_model.py:152-193)
+// Every float operation of the reference's torch expression chain is one correctly rounded f32 operation here, in the
+// same order, so the integer voxel coordinates are identical.  hipcc contracts a * b + c into an FMA by default
+// (-ffp-contract=fast), and HIP's __fmul_rn / __fadd_rn do not help (they are plain `*` / `+` defined in a header,
+// i.e. under the default): the kernels switch contraction off and use the bare operators.
+__global__ void pv_gather_kernel(int S, const long long *__restrict__ clusters_idx, const float *__restrict__ coords,
+                                 float *__restrict__ xyz)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const long long pt = clusters_idx[(size_t)s * 2 + 1];
+#pragma unroll
+    for (int c = 0; c < 3; c++) xyz[(size_t)s * 3 + c] = coords[(size_t)pt * 3 + c];
+}
+
+// per proposal: min / max of the centred coordinates -> scale and shift   (params[p] = scale, shift x, y, z)
+__global__ __launch_bounds__(256) void pv_params_kernel(int P, const int *__restrict__ offsets,
+                                                        const float *__restrict__ xyz, const float *__restrict__ mean,
+                                                        float scale_max, float ss, const float *__restrict__ rand6,
+                                                        float *__restrict__ params)
+{
+#pragma clang fp contract(off)
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        const int b = offsets[p], e = offsets[p + 1];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const float m0 = mean[p * 3 + 0], m1 = mean[p * 3 + 1], m2 = mean[p * 3 + 2];
+        for (int s = b + threadIdx.x; s < e; s += blockDim.x) {
+            const float d0 = (xyz[(size_t)s * 3 + 0] - m0), d1 = (xyz[(size_t)s * 3 + 1] - m1),
+                        d2 = (xyz[(size_t)s * 3 + 2] - m2);
+            lo[0] = fminf(lo[0], d0); lo[1] = fminf(lo[1], d1); lo[2] = fminf(lo[2], d2);
+            hi[0] = fmaxf(hi[0], d0); hi[1] = fmaxf(hi[1], d1); hi[2] = fmaxf(hi[2], d2);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = wave_min_f(lo[c]);
+            hi[c] = wave_max_f(hi[c]);
+        }
+        __syncthreads();
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                s_lo[wave_id()][c] = lo[c];
+                s_hi[wave_id()][c] = hi[c];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float l[3], h[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                l[c] = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+                h[c] = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+            }
+            // c_scale = clamp(1 / max_c((hi - lo) / spatial_shape) - 0.01, max = scale)
+            float r = ((h[0] - l[0]) / ss);
+            r = fmaxf(r, ((h[1] - l[1]) / ss));
+            r = fmaxf(r, ((h[2] - l[2]) / ss));
+            float cs = ((1.f / r) - 0.01f);
+            cs = cs > scale_max ? scale_max : cs;
+            params[p * 4 + 0] = cs;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float ls = (l[c] * cs), hs = (h[c] * cs);
+                const float room = (ss - (hs - ls));   // spatial_shape - extent
+                float t1 = (room - 0.001f);
+                t1 = t1 < 0.f ? 0.f : t1;                                // clamp(min = 0)
+                float t2 = (room + 0.001f);
+                t2 = t2 > 0.f ? 0.f : t2;                                // clamp(max = 0)
+                const float sh = (-ls + (t1 * rand6[c]));
+                params[p * 4 + 1 + c] = (sh + (t2 * rand6[3 + c]));
+            }
+        }
+    }
+}
+
+__global__ void pv_emit_kernel(int S, const long long *__restrict__ clusters_idx, const float *__restrict__ xyz,
+                               const float *__restrict__ mean, const float *__restrict__ params, int *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int p = (int)clusters_idx[(size_t)s * 2];
+    const float cs = params[p * 4];
+    int4 o;
+    o.x = p;
+    o.y = (int)(((xyz[(size_t)s * 3 + 0] - mean[p * 3 + 0]) * cs) + params[p * 4 + 1]);
+    o.z = (int)(((xyz[(size_t)s * 3 + 1] - mean[p * 3 + 1]) * cs) + params[p * 4 + 2]);
+    o.w = (int)(((xyz[(size_t)s * 3 + 2] - mean[p * 3 + 2]) * cs) + params[p * 4 + 3]);
+    reinterpret_cast<int4 *>(out)[s] = o;
+}
+
 inline int grid_for(int P) { return max(1, min(ms3d_divup(P, WAVES_PER_BLOCK), 4096)); }
 inline bool use_block_kernel(int C) { return (C & (C - 1)) == 0 && C >= 8 && C <= 64; }
 
@@ -308,6 +400,24 @@ int ms3d_global_avg_pool_bp(int P, int C, float *d_feats, const int *offsets, co
 {
     if (P <= 0 || C <= 0) return 0;
     avg_pool_bp_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, offsets, d_out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_proposal_voxel_coords(const long long *clusters_idx, int S, const int *offsets, int P, const float *coords,
+                               float scale, int spatial_shape, const float *rand6, float *xyz_ws, float *mean_ws,
+                               float *param_ws, int *out, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (S <= 0 || P <= 0) return 0;
+    pv_gather_kernel<<<ms3d_divup(S, 256), 256, 0, stream>>>(S, clusters_idx, coords, xyz_ws);
+    MS3D_LAUNCH_CHECK();
+    seg_serial_sum_kernel<OP_MEAN><<<grid_for(P), 256, 0, stream>>>(P, 3, xyz_ws, offsets, mean_ws);
+    MS3D_LAUNCH_CHECK();
+    pv_params_kernel<<<P < 2048 ? P : 2048, 256, 0, stream>>>(P, offsets, xyz_ws, mean_ws, scale, (float)spatial_shape, rand6,
+                                                             param_ws);
+    MS3D_LAUNCH_CHECK();
+    pv_emit_kernel<<<ms3d_divup(S, 256), 256, 0, stream>>>(S, clusters_idx, xyz_ws, mean_ws, param_ws, out);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

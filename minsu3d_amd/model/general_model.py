@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import MinkowskiEngine as ME
+from ..backend import get_backend
 from ..common_ops.functions import common_ops
 from ..loss import PTOffsetLoss
 from .module import Backbone
@@ -88,14 +89,12 @@ def scene_offsets(batch_idxs, n_scenes):
     return torch.cumsum(counts, dim=0).int()
 
 
-def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None):
-    """Per-proposal recentre / rescale into a `spatial_shape` cube, random placement, integer cast, dedupe into
-    voxels (reference general_model.py:152-193).  `rand` = the two U(0,1)^3 draws shared by all proposals
-    (injected by parity tests, SURVEY B.5).  -> (SparseTensor over proposal voxels, point->voxel map)"""
+def proposal_voxel_coords_torch(clusters_idx, clusters_offset, coords, scale, spatial_shape, u1, u2):
+    """the reference's expression chain (general_model.py:152-181) in torch operators -> i32 [S, 4] (proposal, x, y, z).
+    The semantics the fused device operator (`HipBackend.proposal_voxel_coords`) is tested against, and what CPU
+    tensors take (test double backends)."""
     cluster_of = clusters_idx[:, 0].long()
-    point_of = clusters_idx[:, 1].long()
-    feats = ME.gather_rows(feats, point_of)
-    xyz = coords[point_of]
+    xyz = coords[clusters_idx[:, 1].long()]
     xyz = xyz - common_ops.sec_mean(xyz.contiguous(), clusters_offset)[cluster_of]
     lo = common_ops.sec_min(xyz.contiguous(), clusters_offset)
     hi = common_ops.sec_max(xyz.contiguous(), clusters_offset)
@@ -104,11 +103,28 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
     lo, hi = lo * c_scale[:, None], hi * c_scale[:, None]
     xyz = xyz * c_scale[cluster_of][:, None]
     extent = hi - lo
-    u1, u2 = rand if rand is not None else (torch.rand(3, device=device), torch.rand(3, device=device))
     shift = -lo + torch.clamp(spatial_shape - extent - 0.001, min=0) * u1
     shift = shift + torch.clamp(spatial_shape - extent + 0.001, max=0) * u2
     vox = (xyz + shift[cluster_of]).int()
-    batched = torch.cat((clusters_idx[:, 0].int().unsqueeze(-1), vox), dim=1).contiguous()
+    return torch.cat((clusters_idx[:, 0].int().unsqueeze(-1), vox), dim=1).contiguous()
+
+
+def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None):
+    """Per-proposal recentre / rescale into a `spatial_shape` cube, random placement, integer cast, dedupe into
+    voxels (reference general_model.py:152-193).  `rand` = the two U(0,1)^3 draws shared by all proposals
+    (injected by parity tests, SURVEY B.5).  -> (SparseTensor over proposal voxels, point->voxel map)"""
+    feats = ME.gather_rows(feats, clusters_idx[:, 1].long())
+    if rand is not None:
+        u = torch.cat((rand[0].reshape(3), rand[1].reshape(3))).to(device=coords.device, dtype=torch.float32)
+    else:
+        u = torch.rand(6, device=coords.device)       # the reference's two torch.rand(3) draws
+    if coords.is_cuda:
+        # one library call (4 launches) instead of ~30 elementwise / gather / segment launches between the grouping's
+        # last host round trip and the ScoreNet, where the GPU waits for the interpreter
+        batched = get_backend().proposal_voxel_coords(clusters_idx.contiguous(), clusters_offset, coords.contiguous(),
+                                                      scale, spatial_shape, u)
+    else:
+        batched = proposal_voxel_coords_torch(clusters_idx, clusters_offset, coords, scale, spatial_shape, u[:3], u[3:])
     voxel_xyz, voxel_feats, _, p2v = ME.utils.sparse_quantize(batched, feats, return_index=True, return_inverse=True,
                                                               device=device.type)
     return ME.SparseTensor(features=voxel_feats, coordinates=voxel_xyz, device=device), p2v

@@ -204,3 +204,33 @@ def test_prefetched_coordinate_structures_give_the_same_forward():
         assert torch.equal(o["semantic_scores"], ref["semantic_scores"])
         assert torch.equal(o["point_offsets"], ref["point_offsets"])
         assert torch.equal(o["proposal_scores"][1], ref["proposal_scores"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_proposal_voxel_coords_fused_vs_expression_chain(seed):
+    """the fused device operator against the reference's expression chain in torch operators (general_model.py:152-181)
+    on the same device: identical integer voxel coordinates -- proposals of 1 point (zero extent: the scale clamps at
+    `scale`), of two points, of thousands, with shared points, scaled up and scaled down"""
+    from minsu3d_amd.backend import get_backend
+    from minsu3d_amd.model.general_model import proposal_voxel_coords_torch
+    g = torch.Generator().manual_seed(seed)
+    n = 60000
+    coords = (torch.rand(n, 3, generator=g) * torch.tensor([8.0, 6.0, 3.0])).cuda()
+    sizes = [1, 2, 3, 17, 64, 65, 500, 4097, 20000, 1] + torch.randint(1, 3000, (120,), generator=g).tolist()
+    idx, off = [], [0]
+    for p, sz in enumerate(sizes):
+        centre = torch.rand(3, generator=g) * torch.tensor([8.0, 6.0, 3.0])
+        radius = float(torch.rand(1, generator=g)) * (0.02 if p % 7 == 0 else 2.0) + 0.005   # tiny ones scale up to the clamp
+        near = torch.nonzero(((coords.cpu() - centre).abs() < radius).all(1)).view(-1)
+        pick = near[torch.randperm(near.numel(), generator=g)[:sz]] if near.numel() >= sz else torch.randint(0, n, (sz,), generator=g)
+        idx.append(torch.stack((torch.full((pick.numel(),), p, dtype=torch.int64), pick.long()), 1))
+        off.append(off[-1] + pick.numel())
+    idx = torch.cat(idx).cuda().contiguous()
+    off = torch.tensor(off, dtype=torch.int32).cuda()
+    u = torch.rand(6, generator=g).cuda()
+    for scale, ss in ((50, 14), (15, 20), (3, 128)):
+        want = proposal_voxel_coords_torch(idx, off, coords, scale, ss, u[:3], u[3:])
+        got = get_backend().proposal_voxel_coords(idx, off, coords, scale, ss, u)
+        assert got.dtype == torch.int32 and torch.equal(got, want)
+        assert int(got[:, 1:].min()) >= 0 and int(got[:, 1:].max()) < ss
