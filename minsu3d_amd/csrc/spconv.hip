@@ -44,7 +44,6 @@ struct ConvArgs {
     const float *in;         // [Vin, Cin]
     const float *wf;         // fragment-major weights
     const float *wfs;        // the same weights in streamed order (prep_weights_kernel) or null
-    int dbg;                 // MS3D_PS_DBG experiments (timing only, wrong results): 1 no MFMA, 2 no accumulate, 4 no weight loads, 8 no row gathers
     const int *nbr;          // [K][Vout]
     float *out;              // [Vout, Cout]
     const float *pre_scale;  // [Cin] or null : a = max(0, x*scale + shift)
@@ -936,7 +935,6 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
                 return tile_entries[(size_t)(c + min((l >> 4) & 1, n - 1)) * 16 + jl];
             };
             auto load_w = [&](int k, int g, f32x4 (&w)[CG][NBT]) {
-                if (p.dbg & 4) k = 0;
 #pragma unroll
                 for (int ch = 0; ch < CG; ch++)
 #pragma unroll
@@ -947,7 +945,6 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     int in_row = __builtin_amdgcn_ds_bpermute((i * 16 + jl) << 2, e.x);
-                    if (p.dbg & 8) in_row = jl;
                     const float *row = p.in + (size_t)in_row * (size_t)p.Cin + 16 * g * CG + 4 * q;
 #pragma unroll
                     for (int ch = 0; ch < CG; ch++) a[i][ch] = *reinterpret_cast<const f32x4 *>(row + 16 * ch);
@@ -994,7 +991,6 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
                             }
                     }
                 }
-                if (!(p.dbg & 1)) {
 #pragma unroll
                 for (int ch = 0; ch < CG; ch++)
 #pragma unroll
@@ -1002,8 +998,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
 #pragma unroll
                         for (int nb = 0; nb < NBT; nb++)
                             d[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[ch][nb][t], a_cur[0][ch][t], d[0][nb], 0, 0, 0);
-                }
-                if (n > 1 && !(p.dbg & 1)) {
+                if (n > 1) {
 #pragma unroll
                     for (int ch = 0; ch < CG; ch++)
 #pragma unroll
@@ -1012,7 +1007,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
                             for (int nb = 0; nb < NBT; nb++)
                                 d[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[ch][nb][t], a_cur[1][ch][t], d[1][nb], 0, 0, 0);
                 }
-                if (last_g && !(p.dbg & 2)) {
+                if (last_g) {
                     // D^T layout: row = output channel 4q + r, column = pair jl -> 16 contiguous bytes of the pair's row;
                     // plain read-modify-write (one writer per tile, LDS operations execute in order, pads -> dummy row)
 #pragma unroll
@@ -1966,8 +1961,6 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     if (g.stream) {
         if (!wf_stream) return MS3D_E_UNSUPPORTED;  // the geometry (and the caller's partial buffer) assume this kernel
         p.wfs = wf_stream;
-        static const int dbg = [] { const char *e = getenv("MS3D_PS_DBG"); return e ? atoi(e) : 0; }();
-        p.dbg = dbg;
 #define MS3D_PS(NBT_, CG_) \
     if (g.nbt == NBT_ && g.cg == CG_) return launch_fwd_pairstream<NBT_, CG_>(p, grid, g.threads, g.lds, stream);
         MS3D_PS(1, 1) MS3D_PS(1, 2) MS3D_PS(1, 3) MS3D_PS(1, 4)
