@@ -50,7 +50,19 @@ class GeneralModel(nn.Module):
     def forward(self, data_dict):
         return self.backbone(data_dict["voxel_features"], data_dict["voxel_xyz"], data_dict["voxel_point_map"])
 
+    def _queue_point_losses(self, data_dict, output_dict):
+        """Scheduling only: the per-point losses need nothing but the backbone's outputs, so the grouping models put their
+        ~30 small launches on the stream right after the backbone -- where the interpreter is milliseconds ahead of the
+        GPU -- instead of after the ScoreNet, where the GPU has run dry at the grouping's last host round trip and waits
+        for every launch.  `_loss` picks the result up."""
+        if torch.is_grad_enabled() and "sem_labels" in data_dict and "instance_center_xyz" in data_dict:
+            output_dict["_point_losses"] = self._point_losses(data_dict, output_dict)
+
     def _loss(self, data_dict, output_dict):
+        queued = output_dict.pop("_point_losses", None)
+        return queued if queued is not None else self._point_losses(data_dict, output_dict)
+
+    def _point_losses(self, data_dict, output_dict):
         # cross entropy with ignore_index = -1 (reference general_model.py:39-41), written as log-softmax + gather:
         # torch's fused nll_loss forward reduces 10^5..10^6 rows in a single block
         labels = data_dict["sem_labels"].long()

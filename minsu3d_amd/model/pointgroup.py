@@ -32,6 +32,7 @@ class PointGroup(GeneralModel):
 
     def forward(self, data_dict):
         out = super().forward(data_dict)
+        self._queue_point_losses(data_dict, out)
         cfg = self.hparams.cfg
         net = cfg.model.network
         if self.current_epoch <= net.prepare_epochs:

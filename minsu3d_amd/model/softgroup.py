@@ -94,6 +94,7 @@ class SoftGroup(GeneralModel):
 
     def forward(self, data_dict):
         out = super().forward(data_dict)
+        self._queue_point_losses(data_dict, out)
         net = self.hparams.cfg.model.network
         if self.current_epoch <= net.prepare_epochs:
             return out
