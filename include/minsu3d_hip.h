@@ -122,6 +122,10 @@ int ms3d_global_avg_pool_fp(int nProposal, int C, const float *feats, const int 
 int ms3d_global_avg_pool_bp(int nProposal, int C, float *d_feats, const int *proposals_offset,
                             const float *d_output_feats, ms3d_stream_t stream);
 
+/* out[i, :] = x[idx[i], :] (f32 rows, int64 index): the forward of the row gathers whose backward is
+ * ms3d_scatter_add_rows (`features[v2p_map]`, backbone.py:40; `feats[p2v]`, pointgroup.py:89) */
+int ms3d_gather_rows(const float *x, const long long *idx /* int64 */, long n, int C, float *out, ms3d_stream_t stream);
+
 /* dst[idx[i], :] += src[i, :] (dst pre-zeroed by the caller): backward of the row gathers features[v2p_map],
  * feats[c_idxs], features[p2v_map] (reference backbone.py:40, general_model.py:156, pointgroup.py:88) */
 int ms3d_scatter_add_rows(const float *src, const long long *idx /* int64 */, long n, int C, float *dst,

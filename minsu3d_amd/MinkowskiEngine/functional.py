@@ -132,6 +132,13 @@ def dense_linear(x, weight, bias):
     return DenseLinearFn.apply(x, weight, bias)
 
 
+def _rows(x, idx):
+    """x[idx]: the library's row gather for device f32 rows (copy speed), torch indexing otherwise"""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and idx.dim() == 1 and idx.dtype == torch.int64:
+        return get_backend().gather_rows(x, idx)
+    return x[idx]
+
+
 class GatherRowsFn(torch.autograd.Function):
     """y = x[idx] with a many-to-one index (voxel -> points).  torch's backward (index_put_ with accumulate) sorts the
     indices on every call; here the backward is one scatter-add kernel."""
@@ -140,7 +147,7 @@ class GatherRowsFn(torch.autograd.Function):
     def forward(ctx, x, idx):
         ctx.save_for_backward(idx)
         ctx.n_rows = x.size(0)
-        return x[idx]
+        return _rows(x, idx)
 
     @staticmethod
     def backward(ctx, dy):
@@ -154,16 +161,16 @@ class PermuteRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, inv, perm):
         ctx.save_for_backward(perm)
-        return x[inv]
+        return _rows(x, inv)
 
     @staticmethod
     def backward(ctx, dy):
         (perm,) = ctx.saved_tensors
-        return dy[perm], None, None
+        return _rows(dy, perm), None, None
 
 
 def gather_rows(x, idx):
     """differentiable x[idx] for 2-D float features and an int64 row index"""
     if x.dim() == 2 and idx.dim() == 1 and idx.dtype == torch.int64 and x.requires_grad:
         return GatherRowsFn.apply(x, idx)
-    return x[idx]
+    return _rows(x, idx) if x.dim() == 2 and idx.dim() == 1 else x[idx]

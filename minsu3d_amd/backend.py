@@ -294,6 +294,16 @@ class HipBackend:
         _lib.check(rc, "ms3d_global_avg_pool_bp")
         return d_feats
 
+    def gather_rows(self, x, idx):
+        """x[idx] for f32 [V, C] rows and an int64 index, at copy speed"""
+        x = self._dev(x); idx = self._dev(idx)
+        assert idx.dtype == torch.int64 and x.dtype == torch.float32 and x.dim() == 2
+        x = x.contiguous(); idx = idx.contiguous()
+        out = torch.empty((idx.numel(), x.size(1)), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.ms3d_gather_rows(_lib.ptr(x), _lib.ptr(idx), C.c_long(idx.numel()), int(x.size(1)), _lib.ptr(out),
+                                             _lib.stream_handle()), "ms3d_gather_rows")
+        return out
+
     def scatter_add_rows(self, src, idx, n_rows):
         """dst[idx[i]] += src[i] -> dst [n_rows, C]; float atomics (order-dependent rounding, within fp32 noise)"""
         src = self._dev(src); idx = self._dev(idx)

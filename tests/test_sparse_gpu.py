@@ -396,3 +396,18 @@ def test_out_of_range_coordinates_are_rejected(be):
     c[1, 0] = 600000
     with pytest.raises(HipLibraryError, match="10002"):
         be.downsample(c, 1)
+
+
+@pytest.mark.parametrize("C_", [1, 3, 6, 16, 20, 32, 112])
+def test_gather_rows_vs_torch_indexing(be, C_):
+    """the library's row gather (forward of x[idx]; the backward is scatter_add_rows) against torch indexing: every
+    channel width of the model incl. widths that are not a multiple of 4, repeated and out-of-order indices, empty index"""
+    g = torch.Generator().manual_seed(C_)
+    x = torch.randn(5000, C_, generator=g).cuda()
+    for n in (0, 1, 4097, 30000):
+        idx = torch.randint(0, 5000, (n,), generator=g).cuda()
+        got = be.gather_rows(x, idx)
+        assert got.shape == (n, C_) and torch.equal(got, x[idx])
+    v = x[:, : max(C_ - 1, 1)]                               # a non-contiguous view is made contiguous first
+    idx = torch.randint(0, 5000, (777,), generator=g).cuda()
+    assert torch.equal(be.gather_rows(v, idx), v[idx])
