@@ -323,6 +323,16 @@ int ms3d_nms_greedy(const int *inter, const int *order, int P, float threshold, 
 int ms3d_elastic_distort(const double *xyz /*[N,3]*/, int N, float *noise, float *noise_tmp, int bx, int by, int bz,
                          double gran, double mag, double *out /*[N,3]*/, ms3d_stream_t stream);
 
+/* ---- optimizer: one Adam step over all parameter tensors of a model in one launch (the reference's optimizer is
+ * torch.optim.Adam through Hydra, config/model/base.yaml:23-28; arithmetic as torch's fused Adam, f32).
+ * chunks: int2 (tensor, chunk index) per workgroup, ms3d_adam_chunk_elems() elements per chunk; p / g / m / v: device
+ * arrays of device pointers (parameter, gradient, exp_avg, exp_avg_sq), sizes: elements per tensor (device, int64).
+ * bias_correction_i = 1 - beta_i^step. */
+int ms3d_adam_chunk_elems(void);
+int ms3d_adam_step(const int *chunks, int n_chunks, void *const *p_ptrs, const void *const *g_ptrs, void *const *m_ptrs,
+                   void *const *v_ptrs, const long *sizes, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, double bias_correction1, double bias_correction2, ms3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 Lightning: `hparams.cfg`, `current_epoch`, forward / _loss / training_step / configure_optimizers /
 on_train_epoch_end.  Also the proposal voxelisation and the score-target helper."""
 import importlib
+import os
 import math
 from types import SimpleNamespace
 
@@ -34,7 +35,11 @@ class GeneralModel(nn.Module):
         opt = dict(self.hparams.cfg.model.optimizer)
         mod, _, name = opt.pop("_target_").rpartition(".")
         params = list(self.parameters())
-        if name in ("Adam", "AdamW") and "fused" not in opt and params and params[0].is_cuda:
+        on_gpu = bool(params) and params[0].is_cuda
+        if mod == "torch.optim" and name == "Adam" and on_gpu and os.environ.get("MS3D_ADAM", "1") != "0":
+            from ..optim import Adam            # same state and arithmetic, ONE launch for all parameter tensors
+            return Adam(params, **opt)
+        if name in ("Adam", "AdamW") and "fused" not in opt and on_gpu:
             opt["fused"] = True   # one launch per step instead of ~30 foreach launches with host gaps in between
         return getattr(importlib.import_module(mod), name)(params=params, **opt)
 

@@ -234,3 +234,36 @@ def test_proposal_voxel_coords_fused_vs_expression_chain(seed):
         got = get_backend().proposal_voxel_coords(idx, off, coords, scale, ss, u)
         assert got.dtype == torch.int32 and torch.equal(got, want)
         assert int(got[:, 1:].min()) >= 0 and int(got[:, 1:].max()) < ss
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_matches_torch_adam():
+    """minsu3d_amd.optim.Adam (one library launch per step) against torch.optim.Adam on the same parameters and
+    gradients: tensors of 1 .. 300k elements (chunk boundaries, odd sizes), a sliced (unaligned) gradient, weight decay,
+    20 steps with a changing learning rate; the optimizer states are interchangeable"""
+    from minsu3d_amd.optim import Adam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1,), (3,), (16,), (17, 3), (4096,), (4097,), (27, 16, 16), (300001,), (8192, 2)]
+    for wd in (0.0, 0.01):
+        pa = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        oa = Adam(pa, lr=1e-3, weight_decay=wd)
+        ob = torch.optim.Adam(pb, lr=1e-3, weight_decay=wd)
+        for step in range(20):
+            for grp in (oa.param_groups[0], ob.param_groups[0]):
+                grp["lr"] = 1e-3 * (1.0 - 0.03 * step)
+            for a, b in zip(pa, pb):
+                grad = torch.randn(a.numel() + 1, generator=g).cuda()
+                a.grad = grad[1:].view_as(a) if a.numel() % 2 else grad[:-1].view_as(a).clone()   # odd sizes: 4-byte aligned only
+                b.grad = a.grad.clone()
+            oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+            assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=2e-5, atol=1e-12)   # 20 steps of f32 rounding (torch: separate mul_ and addcmul_)
+            assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 20.0
+        ob.load_state_dict(oa.state_dict())          # torch's Adam continues from our state, and the other way round
+        oa.load_state_dict(ob.state_dict())
+        for a in pa:
+            a.grad = torch.ones_like(a)
+        oa.step()
+        assert float(oa.state[pa[0]]["step"]) == 21.0
