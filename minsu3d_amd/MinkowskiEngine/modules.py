@@ -40,8 +40,13 @@ def prepare_conv_weights(root):
     if not hasattr(be, "prep_weights_multi") or os.environ.get("MS3D_WEIGHT_MULTI", "1") == "0":
         return
     layers = []
-    for m in root.modules():
-        if isinstance(m, _ConvBase) and m.kernel.is_cuda:
+    convs = root.__dict__.get("_ms3d_convs")
+    if convs is None:
+        # (walking the module tree costs 0.7 ms per step on the 400-module networks; the set of convolutions of a built
+        # model does not change -- `del model._ms3d_convs` after surgery on it)
+        convs = root.__dict__["_ms3d_convs"] = tuple(m for m in root.modules() if isinstance(m, _ConvBase))
+    for m in convs:
+        if m.kernel.is_cuda:
             K, cin, cout = m.kernel_volume, m.in_channels, m.out_channels
             if m.kernel.dim() == 2:
                 K = 1

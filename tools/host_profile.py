@@ -13,4 +13,4 @@ pr.enable()
 for i in range(10): bench.train_step(model, model, opt, batches[i % 4])
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
