@@ -121,6 +121,12 @@ class HipBackend:
         n_active, capped = C.c_int(0), C.c_int(0)
         timer = self.kernel_timer
         ev0 = timer.op_begin() if timer is not None else None
+        # The reference's retry loop (common_ops.py:31-38) starts from the configured meanActive on every call; a call
+        # site whose lists outgrow it (SoftGroup's batched per-class query) would run the whole query twice per step.
+        # The first guess therefore remembers what the same call site (radius, configured value) needed last time.
+        hint_key = (round(float(radius), 6), int(meanActive))
+        hints = self.__dict__.setdefault("_bq_mean_active", {})
+        meanActive = max(int(meanActive), hints.get(hint_key, 0))
         while True:
             idx = torch.empty(n * meanActive, dtype=torch.int32, device=dev)
             rc = self.lib.ms3d_ballquery_batch_p(
@@ -132,6 +138,7 @@ class HipBackend:
             if n_active.value <= n * meanActive:
                 break
             meanActive = int(n_active.value // n + 1)
+            hints[hint_key] = meanActive + meanActive // 8 + 1     # 12 % head room for the next batches
         if ev0 is not None:
             # n*12 + n*27*c*12 + nActive*4 + n*8; 27*c = candidates per query = hits * 27*1.01^3 / (4/3 pi)
             timer.op_end("ballquery_batch_p", ev0, n * 20 + n_active.value * (6.64 * 12 + 4))
