@@ -152,9 +152,15 @@ class MinkowskiBatchNorm(nn.Module):
                     mom = bn.momentum
                 g = bn.weight.detach() if bn.affine else None
                 b = bn.bias.detach() if bn.affine else None
-                if x._stats is not None and x._stats.numel() > 0 and x._pending is None:
+                st = x._stats
+                if isinstance(st, tuple) and x._pending is None and hasattr(get_backend(), "bn_finalize_parts") \
+                        and sum(p.size(2) for p in st) == feats.size(1):
+                    # a concatenation of convolution outputs (ME.cat): finalize every part's partials into its slice
+                    mean, invstd, scale, shift = get_backend().bn_finalize_parts(st, feats.size(0), bn.eps, mom, g, b,
+                                                                                 rm, rv)
+                elif torch.is_tensor(st) and st.numel() > 0 and x._pending is None:
                     # the convolution that produced these rows already summed them in its epilogue
-                    mean, invstd, scale, shift = get_backend().bn_finalize(x._stats, feats.size(0), bn.eps, mom, g, b,
+                    mean, invstd, scale, shift = get_backend().bn_finalize(st, feats.size(0), bn.eps, mom, g, b,
                                                                            rm, rv)
                 else:
                     mean, invstd, scale, shift = get_backend().bn_stats(feats.detach(), bn.eps, mom, g, b, rm, rv)

@@ -224,4 +224,10 @@ class SparseTensor:
 
 def cat(*tensors):
     """ME.cat: channel concat of tensors sharing one coordinate map (common.py:93)"""
-    return tensors[0]._like(torch.cat([t._raw() for t in tensors], dim=1))
+    parts = [t._stats if (t._pending is None and torch.is_tensor(t._stats) and t._stats.numel() > 0) else None
+             for t in tensors]
+    # every part still carries the (sum, sum of squares) partials its convolution left behind: the statistics of the
+    # concatenation are the parts' statistics side by side -- the BatchNorm that follows (ResidualBlock after the
+    # U-Net's skip concat) finalizes them per part instead of running a statistics pass over the 2c-wide rows
+    stats = tuple(parts) if all(p is not None for p in parts) else None
+    return tensors[0]._like(torch.cat([t._raw() for t in tensors], dim=1), stats=stats)

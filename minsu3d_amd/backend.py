@@ -800,6 +800,24 @@ class _HipEngine:
                                                   _lib.stream_handle()), "ms3d_bn_finalize")
         return outs.unbind(0)
 
+    def bn_finalize_parts(self, partials, V, eps, momentum, gamma, beta, running_mean, running_var):
+        """bn_finalize over the channel-wise concatenation of several partial buffers (ME.cat of convolution outputs):
+        one finalize launch per part, each on its slice of the parameters, running statistics and outputs"""
+        C_ = sum(int(p.size(2)) for p in partials)
+        outs = torch.empty((4, C_), dtype=torch.float32, device=partials[0].device)
+        base, row = outs.data_ptr(), 4 * C_
+        gamma, beta = _f32(gamma), _f32(beta)
+        fn, c0 = self._fast("ms3d_bn_finalize"), 0
+        for part in partials:
+            c = int(part.size(2))
+            o = 4 * c0
+            at = lambda t: (t.data_ptr() + o) if t is not None else None
+            _lib.check(fn(_p(part), int(part.size(0)), int(V), c, float(eps), float(momentum), at(gamma), at(beta),
+                          at(running_mean), at(running_var), base + o, base + row + o, base + 2 * row + o,
+                          base + 3 * row + o, _lib.stream_handle()), "ms3d_bn_finalize")
+            c0 += c
+        return outs.unbind(0)
+
     def bn_apply(self, x, scale, shift, relu):
         x = self._dev(x)
         y = torch.empty_like(x)

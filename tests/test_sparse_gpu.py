@@ -411,3 +411,37 @@ def test_gather_rows_vs_torch_indexing(be, C_):
     v = x[:, : max(C_ - 1, 1)]                               # a non-contiguous view is made contiguous first
     idx = torch.randint(0, 5000, (777,), generator=g).cuda()
     assert torch.equal(be.gather_rows(v, idx), v[idx])
+
+
+def test_batchnorm_after_cat_takes_the_parts_statistics(be):
+    """ME.cat of two convolution outputs followed by a training-mode BatchNorm (the U-Net's skip concatenation): the
+    statistics come from the partial sums the two convolutions left behind, finalized per part -- same normalised rows,
+    same running statistics as torch.nn.functional.batch_norm over the concatenated rows; the gradient path is unchanged"""
+    import minsu3d_amd.MinkowskiEngine as ME
+    from minsu3d_amd import backend
+    prev = backend.set_backend(be)
+    try:
+        rng = np.random.default_rng(11)
+        c = surface_coords(rng, 2, 30000, extent=48)
+        feats = dev(rng.standard_normal((c.shape[0], 16)).astype(np.float32))
+        torch.manual_seed(3)
+        conv_a = ME.MinkowskiConvolution(16, 32, kernel_size=3, dimension=3).cuda()
+        conv_b = ME.MinkowskiConvolution(16, 48, kernel_size=3, dimension=3).cuda()
+        bn = ME.MinkowskiBatchNorm(80).cuda()
+        with torch.no_grad():
+            bn.bn.weight.uniform_(0.5, 1.5); bn.bn.bias.uniform_(-0.5, 0.5)
+        for m in (conv_a, conv_b, bn):
+            m.train()
+        x = ME.SparseTensor(feats, dev(c))
+        a, b = conv_a(x), conv_b(x)
+        y = ME.cat(a, b)
+        assert isinstance(y._stats, tuple) and len(y._stats) == 2
+        out = bn(y)
+        got = out.F                                              # materialises the lazy normalisation
+        raw = torch.cat((a.F, b.F), 1)
+        rm, rv = torch.zeros(80, device="cuda"), torch.ones(80, device="cuda")
+        want = torch.nn.functional.batch_norm(raw, rm, rv, bn.bn.weight, bn.bn.bias, True, 0.1, 1e-5)
+        assert rel_err(got, want) < 1e-5
+        assert rel_err(bn.bn.running_mean, rm) < 1e-5 and rel_err(bn.bn.running_var, rv) < 1e-5
+    finally:
+        backend.set_backend(prev)
