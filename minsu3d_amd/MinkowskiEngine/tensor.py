@@ -62,6 +62,7 @@ class CoordinateManager:
         ts = 1
         for lvl in range(n_levels):
             self.k3(ts)
+            self.identity(ts)        # table of the 1x1 projections (ResidualBlock.downsample) of this level
             if lvl + 1 < n_levels:
                 self.k2(ts)
             ts *= 2
