@@ -6,18 +6,25 @@
 // smallest not-yet-visited index, members in queue order, and -- when a neighbour list was cut at
 // 1000 entries -- out-edge reachability on a DIRECTED graph.  Plan:
 //
-//   1. weak components  : lock-free union-find over all label-compatible out-edges, larger root
-//                         hooked under smaller (root = smallest member).  Clusters never cross
-//                         a weak component, and a component smaller than the threshold cannot
-//                         contain a surviving cluster, so only big components are expanded.
-//   2. expansion        : persistent 512-thread workgroups pull components from a work list and
-//                         replay the serial algorithm inside each: seeds in ascending index; a
-//                         level-synchronous BFS whose next frontier is built in exactly the
-//                         serial queue order.  For a frontier chunk every out-edge (parent
-//                         position p, slot s) is visited twice: phase A posts atomicMin(claim[j], p),
-//                         phase B lets the edge with claim[j] == p win; winners are compacted in
-//                         (p, s) order by ballot/prefix-sum, which is the order in which the
-//                         serial loop would have pushed them (lists are ascending in j).
+//   1. weak components  : union-find over all label-compatible out-edges, larger root hooked under
+//                         smaller (root = smallest member): pre-hook under the smallest neighbour,
+//                         a racy sampled link pass with plain stores, and a verify pass over all
+//                         edges that takes an atomic only where two ends still disagree.  Clusters
+//                         never cross a weak component, and a component smaller than the threshold
+//                         cannot contain a surviving cluster, so only big components are expanded.
+//   2. expansion        : three regimes, all reproducing the serial queue order (seeds in ascending
+//                         index; members in (level, parent position, slot) order -- the order in
+//                         which the serial loop would have pushed them, lists being ascending in j):
+//      sparse graphs      persistent 512-thread workgroups pull components from a work list and
+//                         replay the serial algorithm inside each (bfs_expand_kernel): per frontier
+//                         chunk every out-edge is visited twice -- phase A posts atomicMin(claim[j], p),
+//                         phase B lets the edge with claim[j] == p win, winners compacted by
+//                         ballot / prefix sum;
+//      dense symmetric    (no list at the 1000 cap) chip-wide level-synchronous mark / pull / win
+//                         kernels over ALL components at once (glob_*);
+//      dense directed     (capped lists) two chip-wide stages: the weak components expanded from their
+//                         roots with pushed claims (dir_*), then the leftovers labelled by their
+//                         smallest ancestor and expanded per label (dir2_*) -- see the comments there.
 //   3. assembly         : per-seed sizes -> keep flags -> two exclusive scans give cluster ids
 //                         (ascending seed) and output offsets; one pass copies members.
 //
@@ -1189,7 +1196,8 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         if (rc0) return rc0;
     }
     // Dense symmetric graphs (shifted coordinates: hundreds of neighbours per point, a handful of BFS levels)
-    // are expanded by the whole chip level by level; sparse or capped (directed) graphs by the replay kernel.
+    // and dense directed graphs (capped lists) are expanded by the whole chip level by level; sparse graphs by the
+    // per-component replay kernel.
     // When the ball query already told us that no list was capped (capped_hint == 0) nothing has to be read back
     // before the expansion; the frontier size is checked together with the final counts.
     static const bool dbg = getenv("MS3D_DEBUG") != nullptr;
