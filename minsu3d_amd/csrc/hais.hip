@@ -51,10 +51,20 @@ __global__ void ha_describe_kernel(int ncc, const int *__restrict__ cc_idx, cons
             z = coord_shift[i * 3 + 2];
         }
         const int n = min(64, e - q0);
-        for (int k = 0; k < n; k++) {
-            ax += __shfl(x, k, 64);
-            ay += __shfl(y, k, 64);
-            az += __shfl(z, k, 64);
+        if (n == 64) {
+            // full batch: constant lane numbers (v_readlane with an immediate), no loop control between the dependent adds
+#pragma unroll
+            for (int k = 0; k < 64; k++) {
+                ax += __shfl(x, k, 64);
+                ay += __shfl(y, k, 64);
+                az += __shfl(z, k, 64);
+            }
+        } else {
+            for (int k = 0; k < n; k++) {
+                ax += __shfl(x, k, 64);
+                ay += __shfl(y, k, 64);
+                az += __shfl(z, k, 64);
+            }
         }
     }
     if (l != 0) return;
