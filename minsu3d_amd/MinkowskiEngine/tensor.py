@@ -151,6 +151,9 @@ def _take_prefetched(coordinates):
     return cm
 
 
+_SORT_MIN_ROWS = int(os.environ.get("MS3D_SORT_MIN_ROWS", "100000"))
+
+
 class SparseTensor:
     def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1,
                  _pending=None, _stats=None):
@@ -159,7 +162,11 @@ class SparseTensor:
                 features, coordinates = features.to(device), coordinates.to(device)
             coordinate_manager = _take_prefetched(coordinates) if coordinates.is_cuda else None
             if coordinate_manager is None:
-                coordinate_manager = CoordinateManager(coordinates.to(torch.int32), spatial_sort=True)
+                # small tensors (the proposal grids of the score / refinement nets: tens of thousands of rows, a few MB
+                # of features that live in L2 anyway) keep the caller's row order: the Morton sort, the permutation
+                # and its inverse cost more than the locality buys
+                coordinate_manager = CoordinateManager(coordinates.to(torch.int32),
+                                                       spatial_sort=coordinates.size(0) >= _SORT_MIN_ROWS)
             if coordinate_manager.perm is not None:
                 features = features[coordinate_manager.perm]
         self._F = features

@@ -191,10 +191,14 @@ def test_bn_kernels_vs_torch(be, C_):
     assert rel_err(s1s2[0], bn.bias.grad) < 5e-4 and rel_err(s1s2[1], bn.weight.grad) < 5e-4
 
 
-def test_mini_unet_hip_vs_torch(be):
-    """the ME module chain on the HIP backend (fused kernels, custom backward) vs plain torch ops on the GPU"""
+@pytest.mark.parametrize("sort_rows", [0, 1 << 30])
+def test_mini_unet_hip_vs_torch(be, sort_rows, monkeypatch):
+    """the ME module chain on the HIP backend (fused kernels, custom backward) vs plain torch ops on the GPU; with the
+    engine's Morton row order (sort_rows = 0: every tensor is sorted) and in the caller's row order (small tensors)"""
     import minsu3d_amd.MinkowskiEngine as ME
     from minsu3d_amd import backend
+    from minsu3d_amd.MinkowskiEngine import tensor as me_tensor
+    monkeypatch.setattr(me_tensor, "_SORT_MIN_ROWS", sort_rows)
     prev = backend.set_backend(be)
     try:
         rng = np.random.default_rng(5)
