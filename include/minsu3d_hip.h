@@ -121,6 +121,10 @@ int ms3d_global_avg_pool_fp(int nProposal, int C, const float *feats, const int 
                             float *output_feats, ms3d_stream_t stream);
 int ms3d_global_avg_pool_bp(int nProposal, int C, float *d_feats, const int *proposals_offset,
                             const float *d_output_feats, ms3d_stream_t stream);
+/* the same with the number of rows the proposals cover (offsets[nProposal] - offsets[0], which the Python wrapper
+ * knows as sum_npoint, common_ops.py:160): element-parallel launch instead of one wave per proposal */
+int ms3d_global_avg_pool_bp_rows(int nProposal, int C, long n_rows, float *d_feats, const int *proposals_offset,
+                                 const float *d_output_feats, ms3d_stream_t stream);
 
 /* out[i, :] = x[idx[i], :] (f32 rows, int64 index): the forward of the row gathers whose backward is
  * ms3d_scatter_add_rows (`features[v2p_map]`, backbone.py:40; `feats[p2v]`, pointgroup.py:89) */

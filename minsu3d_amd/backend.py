@@ -296,9 +296,9 @@ class HipBackend:
         d_out = self._dev(d_out)
         P, Cc = d_out.shape
         d_feats = torch.zeros((sum_npoint, Cc), dtype=torch.float32, device=d_out.device)
-        rc = self.lib.ms3d_global_avg_pool_bp(P, Cc, _lib.ptr(d_feats), _lib.ptr(offsets), _lib.ptr(d_out),
-                                              _lib.stream_handle())
-        _lib.check(rc, "ms3d_global_avg_pool_bp")
+        rc = self.lib.ms3d_global_avg_pool_bp_rows(P, Cc, C.c_long(int(sum_npoint)), _lib.ptr(d_feats),
+                                                   _lib.ptr(self._dev(offsets)), _lib.ptr(d_out), _lib.stream_handle())
+        _lib.check(rc, "ms3d_global_avg_pool_bp_rows")
         return d_feats
 
     def gather_rows(self, x, idx):

@@ -22,51 +22,138 @@ constexpr int MAX_C_STAGE = 64;  // channels staged per pass
 
 enum SegOp { OP_MEAN = 0, OP_SUM_DIV = 1 };
 
-// sequential-order float accumulation (bit-exact with the reference's serial loops)
+// sequential-order float accumulation (bit-exact with the reference's serial loops).  Lane c owns channel c's chain of
+// dependent adds; the rows travel through LDS in tiles of 2048 floats, the NEXT tile's global loads are in flight while
+// the current tile is added (two LDS buffers), 8 LDS reads are issued per 8 adds.
 template <int OP>
 __global__ __launch_bounds__(256) void seg_serial_sum_kernel(int P, int C, const float *__restrict__ inp,
                                                              const int *__restrict__ offsets,
                                                              float *__restrict__ out)
 {
-    __shared__ float tile[WAVES_PER_BLOCK][TILE_ROWS * MAX_C_STAGE];
+    constexpr int TF = 2048, PER = TF / 64;   // floats per tile, per lane
+    __shared__ float tile[WAVES_PER_BLOCK][2][TF];
     const int w = wave_id(), l = lane_id();
-    float *t = tile[w];
     for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
         const int s = offsets[p], e = offsets[p + 1];
         const float count = (float)(e - s);
         for (int c0 = 0; c0 < C; c0 += MAX_C_STAGE) {
             const int cw = min(MAX_C_STAGE, C - c0);
-            float acc = 0.f;
-            for (int r0 = s; r0 < e; r0 += TILE_ROWS) {
-                const int rows = min(TILE_ROWS, e - r0);
-                // stage rows*cw floats; consecutive lanes read consecutive addresses when cw == C
-                for (int q = l; q < rows * cw; q += 64) {
+            const int rt = TF / cw;                       // rows per tile
+            const int ntiles = (e - s + rt - 1) / rt;
+            float reg[PER];
+            auto load = [&](int ti) {
+                const int r0 = s + ti * rt;
+                const int nfl = min(rt, e - r0) * cw;
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const int q = l + 64 * k;
                     const int r = q / cw, c = q - r * cw;
-                    float v = inp[(size_t)(r0 + r) * C + c0 + c];
+                    // consecutive lanes read consecutive addresses when cw == C
+                    float v = q < nfl ? inp[(size_t)(r0 + r) * C + c0 + c] : 0.f;
                     if (OP == OP_MEAN) v = v / count;  // sec_mean.cu:22 divides before adding
-                    t[r * cw + c] = v;
+                    reg[k] = v;
                 }
+            };
+            auto store = [&](int ti) {
+                float *dst = tile[w][ti & 1];
+#pragma unroll
+                for (int k = 0; k < PER; k++) dst[l + 64 * k] = reg[k];
+            };
+            float acc = 0.f;
+            if (ntiles > 0) {
+                load(0);
+                store(0);
+            }
+            for (int ti = 0; ti < ntiles; ti++) {
+                if (ti + 1 < ntiles) load(ti + 1);          // in flight during the adds below
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave landed
+                __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): this wave's LDS writes of tile ti landed
+                const int rows = min(rt, e - (s + ti * rt));
                 if (l < cw) {
-                    // 8 LDS reads issued together, then added in row order (one read per dependent add paid the LDS
-                    // latency for every member of the proposal)
+                    const float *t = tile[w][ti & 1] + l;
                     int r = 0;
                     for (; r + 8 <= rows; r += 8) {
                         float v[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) v[u] = t[(r + u) * cw + l];
+                        for (int u = 0; u < 8; u++) v[u] = t[(r + u) * cw];
 #pragma unroll
                         for (int u = 0; u < 8; u++) acc += v[u];
                     }
-                    for (; r < rows; r++) acc += t[r * cw + l];
+                    for (; r < rows; r++) acc += t[r * cw];
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (ti + 1 < ntiles) store(ti + 1);
             }
             if (l < cw) {
                 if (OP == OP_SUM_DIV) acc = acc / count;  // roipool.cu:78 sums then divides
                 out[(size_t)p * C + c0 + l] = acc;
             }
+        }
+    }
+}
+
+// The same for 3-channel rows (coordinates: sec_mean in the proposal voxelisation, on the critical path between the
+// grouping and the ScoreNet).  The sum is a chain of dependent adds per channel -- three lanes work, 4-5 cycles per row
+// at best -- so everything else has to stay off that chain: tiles of 256 rows (contiguous memory, 12 floats per lane),
+// the NEXT tile's global loads in flight while the current tile is added, double-buffered in LDS, 32 LDS reads issued
+// per 32 adds.  248 -> ~120 us for the benchmark's proposals (largest ~40k points).
+template <int OP>
+__global__ __launch_bounds__(256) void seg_serial_sum3_kernel(int P, const float *__restrict__ inp,
+                                                              const int *__restrict__ offsets, float *__restrict__ out)
+{
+    constexpr int RT = 256, PER = RT * 3 / 64;   // rows per tile, floats per lane and tile
+    __shared__ float tile[WAVES_PER_BLOCK][2][RT * 3];
+    const int w = wave_id(), l = lane_id();
+    for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
+        const int s = offsets[p], e = offsets[p + 1];
+        const float count = (float)(e - s);
+        const int ntiles = (e - s + RT - 1) / RT;
+        float reg[PER];
+        auto load = [&](int ti) {
+            const int r0 = s + ti * RT;
+            const int nfl = min(RT, e - r0) * 3;
+            const float *src = inp + (size_t)r0 * 3;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int q = l + 64 * k;
+                float v = q < nfl ? src[q] : 0.f;
+                if (OP == OP_MEAN) v = v / count;   // sec_mean.cu:22 divides before adding
+                reg[k] = v;
+            }
+        };
+        auto store = [&](int ti) {
+            float *dst = tile[w][ti & 1];
+#pragma unroll
+            for (int k = 0; k < PER; k++) dst[l + 64 * k] = reg[k];
+        };
+        float acc = 0.f;
+        if (ntiles > 0) {
+            load(0);
+            store(0);
+        }
+        for (int ti = 0; ti < ntiles; ti++) {
+            if (ti + 1 < ntiles) load(ti + 1);          // in flight during the adds below
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): this wave's LDS writes of tile ti landed
+            const int rows = min(RT, e - (s + ti * RT));
+            if (l < 3) {
+                const float *t = tile[w][ti & 1] + l;
+                int r = 0;
+                for (; r + 32 <= rows; r += 32) {
+                    float v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) v[u] = t[(r + u) * 3];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) acc += v[u];
+                }
+                for (; r < rows; r++) acc += t[r * 3];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ti + 1 < ntiles) store(ti + 1);
+        }
+        if (l < 3) {
+            if (OP == OP_SUM_DIV) acc = acc / count;
+            out[(size_t)p * 3 + l] = acc;
         }
     }
 }
@@ -238,10 +325,34 @@ __global__ void roipool_bp_kernel(int P, int C, float *__restrict__ d_feats, con
     atomicAdd(&d_feats[(size_t)am * C + c], d_out[t]);
 }
 
-// proposals own disjoint row ranges, so every d_feats element receives exactly one addend
-__global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, float *__restrict__ d_feats,
+// proposals own disjoint row ranges, so every d_feats element receives exactly one addend.  Element-parallel (a wave
+// per proposal left the chip to the few largest proposals: 207 us): a thread owns one row x 4 channels and finds its
+// proposal by bisection of the offsets (L2 resident).
+__global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, long S, float *__restrict__ d_feats,
                                                           const int *__restrict__ offsets,
                                                           const float *__restrict__ d_out)
+{
+    const int cq = (C + 3) / 4;   // 4-channel groups per row
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * cq) return;
+    const long row = t / cq + offsets[0];
+    if (row >= (long)offsets[P]) return;   // rows behind the last proposal receive nothing
+    const int c0 = (int)(t % cq) * 4;
+    int lo = 0, hi = P;           // largest p with offsets[p] <= row
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)offsets[mid] <= row) lo = mid; else hi = mid;
+    }
+    const float n = (float)(offsets[lo + 1] - offsets[lo]);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (c0 + u < C) d_feats[(size_t)row * C + c0 + u] += d_out[(size_t)lo * C + c0 + u] / n;
+}
+
+// same operator without the row count (the reference's signature): one wave per proposal
+__global__ __launch_bounds__(256) void avg_pool_bp_wave_kernel(int P, int C, float *__restrict__ d_feats,
+                                                               const int *__restrict__ offsets,
+                                                               const float *__restrict__ d_out)
 {
     const int w = wave_id(), l = lane_id();
     for (int p = blockIdx.x * WAVES_PER_BLOCK + w; p < P; p += gridDim.x * WAVES_PER_BLOCK) {
@@ -357,7 +468,10 @@ extern "C" {
 int ms3d_sec_mean(int P, int C, const float *inp, const int *offsets, float *out, ms3d_stream_t stream)
 {
     if (P <= 0 || C <= 0) return 0;
-    seg_serial_sum_kernel<OP_MEAN><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out);
+    if (C == 3)
+        seg_serial_sum3_kernel<OP_MEAN><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, inp, offsets, out);
+    else
+        seg_serial_sum_kernel<OP_MEAN><<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, inp, offsets, out);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -432,7 +546,16 @@ int ms3d_global_avg_pool_bp(int P, int C, float *d_feats, const int *offsets, co
                             ms3d_stream_t stream)
 {
     if (P <= 0 || C <= 0) return 0;
-    avg_pool_bp_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, offsets, d_out);
+    avg_pool_bp_wave_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, offsets, d_out);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+int ms3d_global_avg_pool_bp_rows(int P, int C, long n_rows, float *d_feats, const int *offsets, const float *d_out,
+                                 ms3d_stream_t stream)
+{
+    if (P <= 0 || C <= 0 || n_rows <= 0) return 0;
+    avg_pool_bp_kernel<<<ms3d_divup(n_rows * ((C + 3) / 4), 256), 256, 0, (hipStream_t)stream>>>(P, C, n_rows, d_feats, offsets,
+                                                                                               d_out);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -445,7 +568,7 @@ int ms3d_proposal_voxel_coords(const long long *clusters_idx, int S, const int *
     if (S <= 0 || P <= 0) return 0;
     pv_gather_kernel<<<ms3d_divup(S, 256), 256, 0, stream>>>(S, clusters_idx, coords, xyz_ws);
     MS3D_LAUNCH_CHECK();
-    seg_serial_sum_kernel<OP_MEAN><<<grid_for(P), 256, 0, stream>>>(P, 3, xyz_ws, offsets, mean_ws);
+    seg_serial_sum3_kernel<OP_MEAN><<<grid_for(P), 256, 0, stream>>>(P, xyz_ws, offsets, mean_ws);
     MS3D_LAUNCH_CHECK();
     pv_params_kernel<<<P < 2048 ? P : 2048, 256, 0, stream>>>(P, offsets, xyz_ws, mean_ws, scale, (float)spatial_shape, rand6,
                                                              param_ws);
