@@ -247,9 +247,12 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
  * (sum, sum of squares) of the OUTPUT rows (after the residual add) -> feed ms3d_bn_finalize, no extra pass. */
 int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
                                   float *wf_stream /* or NULL */, float *wft_stream /* or NULL */, ms3d_stream_t stream);
+/* 1 if a layer of this shape can be served by the weight-streaming kernel (then its descriptor in
+ * ms3d_spconv_prep_weights_multi must ask for the streamed images: field `stream`) */
+int ms3d_spconv_wants_stream_image(int K, int Cin, int Cout);
 /* Both images of n layers in ONE launch (a U-Net re-lays ~90 weight tensors per step, ~5 us of dispatch each).
  * descs: device array of n 48-byte records {const float *W; float *wf; float *wft; int K, Cin, Cout, mirror_bwd,
- * block_begin, 0}, block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum.
+ * block_begin, stream}, stream = ms3d_spconv_wants_stream_image(K, Cin, Cout), block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum.
  * wf and wft each have room for 2 * ms3d_spconv_wf_floats() floats: the image, then its streamed form. */
 int ms3d_spconv_prep_blocks(int K, int Cin, int Cout);
 int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, ms3d_stream_t stream);

@@ -691,12 +691,13 @@ class _HipEngine:
         if cached is None or cached[0] != key:
             rec = np.zeros(len(layers), dtype=np.dtype([("W", "<u8"), ("wf", "<u8"), ("wft", "<u8"), ("K", "<i4"),
                                                          ("Cin", "<i4"), ("Cout", "<i4"), ("mirror", "<i4"),
-                                                         ("begin", "<i4"), ("pad", "<i4")]))
+                                                         ("begin", "<i4"), ("stream", "<i4")]))
             begin = 0
             for i, (w, b, K, cin, cout, m) in enumerate(layers):
                 assert w.is_contiguous() and w.dtype == torch.float32 and b.numel() >= self.wf_floats(K, cin, cout)
                 rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * 2 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
-                          K, cin, cout, int(bool(m)), begin, 0)
+                          K, cin, cout, int(bool(m)), begin,
+                          int(self.lib.ms3d_spconv_wants_stream_image(int(K), int(cin), int(cout))))
                 begin += self.lib.ms3d_spconv_prep_blocks(int(K), int(cin), int(cout))
             table = torch.from_numpy(rec.view(np.uint8).copy()).to(layers[0][0].device)
             cached = self._prep_table = (key, table, begin)

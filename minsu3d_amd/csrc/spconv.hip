@@ -129,7 +129,8 @@ struct PrepDesc {
     const float *W;   // [K][Cin][Cout]
     float *wf, *wft;  // forward image, backward-data image (transposed, offsets mirrored if mirror_bwd);
                       // each is followed by its streamed image: wf + n, wft + n  (n = ms3d_spconv_wf_floats)
-    int K, Cin, Cout, mirror_bwd, block_begin, pad;
+    int K, Cin, Cout, mirror_bwd, block_begin;
+    int stream;       // also write the streamed images (only layers that can take spconv_fwd_pairstream_kernel read them)
 };
 static_assert(sizeof(PrepDesc) == 48, "layout shared with the host-side descriptor table");
 
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;
         const float v = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
         d.wf[o] = v;
-        d.wf[total + stream_slot(o, NB)] = v;
+        if (d.stream) d.wf[total + stream_slot(o, NB)] = v;
     }
     {
         long r = o >> 6;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int ks = d.mirror_bwd ? (d.K - 1 - k) : k;
         const float v = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
         d.wft[o] = v;
-        d.wft[total + stream_slot(o, NCH)] = v;
+        if (d.stream) d.wft[total + stream_slot(o, NCH)] = v;
     }
 }
 
@@ -1769,12 +1770,18 @@ bool pairlist_shape_ok(int Vout, int K, int Cin, int Cout)
 // instructions and five dependent LDS / memory waits per 64-MFMA stage (SQ counters: 60 % of the wave cycles in issue
 // stalls) and does not overlap them with the matrix pipe.  So it takes the RECTANGULAR layers (the first convolution
 // after a concatenation and its backward-data twin), where the table walk's column-slice geometry is at its worst.
-bool pairstream_shape_ok(int Vout, int K, int Cin, int Cout)
+// the part of the decision that depends on the layer only (the weight layout kernels write the streamed images for
+// exactly these layers)
+bool pairstream_layer_ok(int K, int Cin, int Cout)
 {
     const int mode = pairstream_mode();   // 3 = every wide layer (experiments)
     const bool on = (mode == 1 && Cin != Cout) || mode == 3 || (mode == 2 && Cin > 64);
-    return on && pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && Vout <= (1 << 22) && K > 1 && K <= 27 &&
-           Cin % 16 == 0 && Cout % 16 == 0 && (Cin > 32 || Cout > 32) && Cin <= 256 && Cout <= 256;
+    return on && pairlist_min_rows() >= 0 && K > 1 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0 && (Cin > 32 || Cout > 32) &&
+           Cin <= 256 && Cout <= 256;
+}
+bool pairstream_shape_ok(int Vout, int K, int Cin, int Cout)
+{
+    return pairstream_layer_ok(K, Cin, Cout) && Vout >= pairlist_min_rows() && Vout <= (1 << 22);
 }
 constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
@@ -1917,6 +1924,12 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
 }  // namespace
 
 extern "C" {
+
+// 1 if a layer of this shape may be served by the weight-streaming kernel (either direction), i.e. needs streamed images
+int ms3d_spconv_wants_stream_image(int K, int Cin, int Cout)
+{
+    return (pairstream_layer_ok(K, Cin, Cout) || pairstream_layer_ok(K, Cout, Cin)) ? 1 : 0;
+}
 
 int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27; }
 

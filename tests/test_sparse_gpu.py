@@ -352,10 +352,18 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
     token = be.weight_token
     be.prep_weights_multi(layers)
     assert be.weight_token == token + 1
+    streamed = 0
     for (W, buf, K, cin, cout, _), (wf, wft) in zip(layers, want):     # buffer = [wf | wf streamed | wft | wft streamed]
-        assert torch.equal(buf.view(2, 2, -1)[0], wf) and torch.equal(buf.view(2, 2, -1)[1], wft), (K, cin, cout)
+        got = buf.view(2, 2, -1)
+        # the streamed images are written only for layers the weight-streaming kernel can serve (48 -> 32 here)
+        rows = slice(0, 2) if be.lib.ms3d_spconv_wants_stream_image(K, cin, cout) else slice(0, 1)
+        streamed += rows.stop - 1
+        assert torch.equal(got[0][rows], wf[rows]) and torch.equal(got[1][rows], wft[rows]), (K, cin, cout)
+        if rows.stop == 1:
+            assert torch.isnan(got[0][1]).all() and torch.isnan(got[1][1]).all()      # untouched
+    assert streamed >= 1
     be.prep_weights_multi(layers[:2])          # a different set of tensors: the descriptor table is rebuilt
-    assert torch.equal(layers[1][1].view(2, 2, -1)[0], want[1][0])
+    assert torch.equal(layers[1][1].view(2, 2, -1)[0][0], want[1][0][0])
 
 
 @pytest.mark.parametrize("cin,cout,level", [(16, 16, 0), (32, 32, 1), (48, 48, 2)])
