@@ -2043,7 +2043,13 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     WgradArgs p;
     p.in = in; p.dout = dout; p.nbr = nbr; p.partial = partial_ws; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout; p.NBtot = ms3d_divup(Cout, 16); p.pre_relu = pre_relu;
-    const int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
+    int chunks = ms3d_spconv_wgrad_row_chunks(Vout);
+    // wide layers: the slab reduction reads chunks x |dW| (64 -> 64: 256 x 442 KB = 113 MB per launch, as much as the
+    // gathers); half the slabs still leave every CU several workgroups (K / KG x Cin / 16 of them per chunk)
+    static const int wide_chunks = [] { const char *e = getenv("MS3D_WGRAD_WIDE_CHUNKS"); return e ? atoi(e) : 128; }();
+    static const int xwide_chunks = [] { const char *e = getenv("MS3D_WGRAD_XWIDE_CHUNKS"); return e ? atoi(e) : 128; }();
+    if (n >= 100000 && chunks > wide_chunks) chunks = wide_chunks;
+    if (n >= 400000 && chunks > xwide_chunks) chunks = xwide_chunks;
     const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
     int nblk;
