@@ -1641,14 +1641,42 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
     __syncthreads();
     const long e_begin = (long)blockIdx.x * rows_per_block * C;
     const long e_end = min(V, (long)(blockIdx.x + 1) * rows_per_block) * C;
-    for (long e = e_begin + threadIdx.x; e < e_end; e += blockDim.x) {
-        const int c = (int)(e % C);
-        const float xv = x[e];
-        float g = dy[e];
-        if (relu && !(fmaf(xv, scale[c], shift[c]) > 0.f)) g = 0.f;
-        dz[e] = g;
-        atomicAdd(&s_acc[c], g);
-        atomicAdd(&s_acc[C + c], g * ((xv - mean[c]) * invstd[c]));
+    if ((C & 3) == 0 && (4 * 256) % C == 0) {
+        // 16 bytes per lane, and the four channels of a thread never change: sums in registers, eight LDS atomics per
+        // thread at the end (two per ELEMENT, ~240 cycles each, made this kernel 133 us for 433k x 32 rows: 7x its traffic)
+        const long v_begin = e_begin >> 2, v_end = e_end >> 2;
+        const int c = (int)((4 * (v_begin + threadIdx.x)) % C);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 2
+        for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
+            const float4 xv = reinterpret_cast<const float4 *>(x)[v];
+            float4 g = reinterpret_cast<const float4 *>(dy)[v];
+            if (relu) {
+                if (!(fmaf(xv.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+                if (!(fmaf(xv.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+                if (!(fmaf(xv.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+                if (!(fmaf(xv.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+            }
+            reinterpret_cast<float4 *>(dz)[v] = g;
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s2.x += g.x * ((xv.x - mu.x) * is.x); s2.y += g.y * ((xv.y - mu.y) * is.y);
+            s2.z += g.z * ((xv.z - mu.z) * is.z); s2.w += g.w * ((xv.w - mu.w) * is.w);
+        }
+        atomicAdd(&s_acc[c + 0], s1.x); atomicAdd(&s_acc[c + 1], s1.y); atomicAdd(&s_acc[c + 2], s1.z); atomicAdd(&s_acc[c + 3], s1.w);
+        atomicAdd(&s_acc[C + c + 0], s2.x); atomicAdd(&s_acc[C + c + 1], s2.y);
+        atomicAdd(&s_acc[C + c + 2], s2.z); atomicAdd(&s_acc[C + c + 3], s2.w);
+    } else {
+        for (long e = e_begin + threadIdx.x; e < e_end; e += blockDim.x) {
+            const int c = (int)(e % C);
+            const float xv = x[e];
+            float g = dy[e];
+            if (relu && !(fmaf(xv, scale[c], shift[c]) > 0.f)) g = 0.f;
+            dz[e] = g;
+            atomicAdd(&s_acc[c], g);
+            atomicAdd(&s_acc[C + c], g * ((xv - mean[c]) * invstd[c]));
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];

@@ -267,3 +267,32 @@ def test_one_launch_adam_matches_torch_adam():
             a.grad = torch.ones_like(a)
         oa.step()
         assert float(oa.state[pa[0]]["step"]) == 21.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_", [16, 32, 20])
+def test_point_batchnorm_relu_matches_torch(C_):
+    """the heads' BatchNorm1d + ReLU through the engine's kernels against torch.nn.BatchNorm1d + ReLU: outputs, input /
+    weight / bias gradients, running statistics; training and evaluation mode"""
+    from minsu3d_amd.model.module.networks import PointBatchNormReLU
+    torch.manual_seed(C_)
+    ours = PointBatchNormReLU(C_).cuda()
+    ref = torch.nn.BatchNorm1d(C_).cuda()
+    with torch.no_grad():
+        ours.weight.uniform_(0.5, 1.5); ours.bias.uniform_(-0.3, 0.3)
+    ref.load_state_dict(ours.state_dict())
+    for train in (True, False):
+        ours.train(train); ref.train(train)
+        x1 = (torch.randn(30000, C_, device="cuda") * 2 + 0.5).requires_grad_(True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        y1, y2 = ours(x1), torch.relu(ref(x2))
+        assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-5)
+        g = torch.randn_like(y1)
+        y1.backward(g); y2.backward(g)
+        assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(ours.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(ours.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+        ours.zero_grad(); ref.zero_grad()
+    assert torch.allclose(ours.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ours.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 1
