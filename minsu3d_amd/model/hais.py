@@ -7,6 +7,7 @@ import torch.nn as nn
 from ..common_ops.functions import common_ops, hais_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
+from .module.networks import PointLinear
 
 
 class HAIS(GeneralModel):
@@ -15,7 +16,8 @@ class HAIS(GeneralModel):
         m = cfg.model.network.m
         self.tiny_unet = TinyUnet(m)
         self.score_branch = nn.Linear(m, 1)
-        self.mask_branch = nn.Sequential(nn.Linear(m, m), nn.ReLU(inplace=True), nn.Linear(m, 1))
+        # (PointLinear = nn.Linear with the same keys; tall-skinny [rows, m] products on the engine's K = 1 path)
+        self.mask_branch = nn.Sequential(PointLinear(m, m), nn.ReLU(inplace=True), PointLinear(m, 1))
         self.voxelization_rand = None
 
     def forward(self, data_dict):

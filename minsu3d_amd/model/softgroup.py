@@ -7,6 +7,7 @@ import torch.nn as nn
 from ..common_ops.functions import common_ops, softgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, scene_offsets
 from .module import TinyUnet
+from .module.networks import PointLinear
 
 
 class SoftGroup(GeneralModel):
@@ -17,7 +18,8 @@ class SoftGroup(GeneralModel):
         k = self.instance_classes + 1
         self.tiny_unet = TinyUnet(m)
         self.classification_branch = nn.Linear(m, k)
-        self.mask_scoring_branch = nn.Sequential(nn.Linear(m, m), nn.ReLU(inplace=True), nn.Linear(m, k))
+        # (PointLinear = nn.Linear with the same keys; tall-skinny [rows, m] products on the engine's K = 1 path)
+        self.mask_scoring_branch = nn.Sequential(PointLinear(m, m), nn.ReLU(inplace=True), PointLinear(m, k))
         self.iou_score = nn.Linear(m, k)
         self.voxelization_rand = None
 
