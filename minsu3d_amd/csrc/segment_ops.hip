@@ -244,7 +244,22 @@ __global__ __launch_bounds__(512) void seg_extreme_block_kernel(int P, int C, co
         const int s = offsets[p], e = offsets[p + 1];
         float best = ident;
         int bi = -1;
-        for (int r = s + w * rstep + rsub; r < e; r += 8 * rstep) {   // ascending rows per lane
+        // ascending rows per lane; 8 loads in flight per lane (one dependent load per step paid a memory round trip for
+        // every 8 * rstep rows of the proposal: 84 us for a 40k-point proposal)
+        const int step = 8 * rstep;
+        int r = s + w * rstep + rsub;
+        for (; r + 7 * step < e; r += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = inp[(size_t)(r + u * step) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (IS_MAX ? (v[u] > best) : (v[u] < best)) {
+                    best = v[u];
+                    bi = r + u * step;
+                }
+        }
+        for (; r < e; r += step) {
             const float v = inp[(size_t)r * C + c];
             if (IS_MAX ? (v > best) : (v < best)) {
                 best = v;
