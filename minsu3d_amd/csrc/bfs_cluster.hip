@@ -281,6 +281,11 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
     __shared__ int s_cnt[NT];
     __shared__ int s_wave[NT / 64];
     __shared__ int s_bcast[2];
+    // sparse graphs: the frontier (list start / length of its nodes) handed from level to level in LDS, two buffers
+    __shared__ int s_fst[2][NT == 512 ? NT : 1], s_fln[2][NT == 512 ? NT : 1];
+    // ... and the claims of a level (<= 512 edges) resolved in an LDS hash table instead of global atomics
+    constexpr int HS = NT == 512 ? 1024 : 1;
+    __shared__ int h_key[HS], h_val[HS];
     const int tid = threadIdx.x;
     constexpr int NW = NT / 64;  // NT = 512 threads for sparse graphs, 1024 for dense / capped ones
     const int nwork = ld_agent(&counters[0]);
@@ -321,8 +326,83 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
             tail += 1;
             int lvl_begin = cluster_start, lvl_end = tail;
             __syncthreads();
+            int fbuf = 0;
+            bool f_valid = false;   // s_fst / s_fln [fbuf] hold the current frontier
             while (lvl_begin < lvl_end) {
                 int new_tail = tail;
+                if (NT == 512 && lvl_end - lvl_begin <= NT) {
+                    // ---- sparse graphs, frontier of at most 512 nodes (every level of an object at 3 cm radius): one edge
+                    // per thread, its target kept in a register from the claim to the win test, the next frontier's list
+                    // headers fetched while the winners are written -- 3-4 dependent memory round trips per level instead
+                    // of 8 (a level is nothing but round trips here: ~200 levels per object).  More than 512 edges in
+                    // the level: the general path below.
+                    const int F = lvl_end - lvl_begin;
+                    if (!f_valid) {
+                        if (tid < F) {
+                            const int node = scratch_node[lvl_begin + tid];
+                            s_fst[fbuf][tid] = start_len[node * 2];
+                            s_fln[fbuf][tid] = start_len[node * 2 + 1];
+                        }
+                        __syncthreads();
+                    }
+                    int E;
+                    const int ex = block_excl_scan_512<NT>(tid < F ? s_fln[fbuf][tid] : 0, &E, s_wave);
+                    if (E <= NT) {
+                        s_pref[tid] = ex;
+                        if (tid == 0) s_pref[NT] = E;
+                        for (int q = tid; q < HS; q += NT) {
+                            h_key[q] = -1;
+                            h_val[q] = INT_BIG;
+                        }
+                        __syncthreads();
+                        int j = -1, lo = 0, slot = 0;
+                        bool ok = false;
+                        if (tid < E) {
+                            int hi = F;  // largest p with pref[p] <= e
+                            while (hi - lo > 1) {
+                                const int mid = (lo + hi) >> 1;
+                                if (s_pref[mid] <= tid) lo = mid; else hi = mid;
+                            }
+                            j = ball_idx[s_fst[fbuf][lo] + (tid - s_pref[lo])];
+                            ok = (thr.mode != 0 || (int)sem[j] == lab) && visited[j] == 0;
+                            if (ok) {
+                                // all edges of the level are in this workgroup: the smallest parent position per target
+                                // is settled in LDS (open addressing, <= 512 keys in 1024 slots), no memory-side atomics
+                                slot = (int)(((unsigned)j * 2654435761u) >> 22) & (HS - 1);
+                                for (;;) {
+                                    const int k = atomicCAS(&h_key[slot], -1, j);
+                                    if (k == -1 || k == j) break;
+                                    slot = (slot + 1) & (HS - 1);
+                                }
+                                atomicMin(&h_val[slot], lo);
+                            }
+                        }
+                        int tot = 0;
+                        if (__syncthreads_or(ok ? 1 : 0)) {
+                            const int win = (ok && h_val[slot] == lo) ? 1 : 0;
+                            const int rank = block_excl_scan_512<NT>(win, &tot, s_wave);
+                            if (win) {
+                                scratch_node[new_tail + rank] = j;
+                                scratch_seed[new_tail + rank] = seed;
+                                visited[j] = 1;
+                                if (rank < NT) {   // (tot <= E <= NT)
+                                    s_fst[fbuf ^ 1][rank] = start_len[j * 2];
+                                    s_fln[fbuf ^ 1][rank] = start_len[j * 2 + 1];
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        fbuf ^= 1;
+                        f_valid = true;
+                        new_tail += tot;
+                        lvl_begin = lvl_end;
+                        lvl_end = new_tail;
+                        tail = new_tail;
+                        continue;
+                    }
+                    __syncthreads();
+                }
+                f_valid = false;
                 for (int c0 = lvl_begin; c0 < lvl_end; c0 += NT) {
                     const int cn = min(NT, lvl_end - c0);
                     // dense lists (capped shifted-coordinate graphs: up to 1000 neighbours) go one wave per frontier node;
