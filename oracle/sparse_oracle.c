@@ -11,7 +11,7 @@
  *   minsu3d/model/module/tiny_unet.py:13-15     general_model.py:187-191
  *   minsu3d/data/data_module.py:94-96           data/dataset/general_dataset.py:159-163
  * and is pinned instead against dense torch.nn.functional.conv3d / conv_transpose3d on
- * densified inputs (tests/test_oracle_sparse.py).
+ * densified inputs (tests/test_sparse_cpu.py).
  *
  * Semantics restated:
  *   sparse_quantize : unique rows of int coords, first occurrence wins, first-occurrence order
