@@ -339,6 +339,11 @@ int ms3d_adam_chunk_elems(void);
 int ms3d_adam_step(const int *chunks, int n_chunks, void *const *p_ptrs, const void *const *g_ptrs, void *const *m_ptrs,
                    void *const *v_ptrs, const long *sizes, float lr, float beta1, float beta2, float eps,
                    float weight_decay, double bias_correction1, double bias_correction2, ms3d_stream_t stream);
+/* the same with a step counter PER TENSOR (torch.optim.Adam starts a parameter's counter with its first gradient):
+ * coef = device float2 per tensor (lr / bias_correction1, sqrt(bias_correction2)) of that tensor's own step */
+int ms3d_adam_step_multi(const int *chunks, int n_chunks, void *const *p_ptrs, const void *const *g_ptrs,
+                         void *const *m_ptrs, void *const *v_ptrs, const long *sizes, const float *coef, float beta1,
+                         float beta2, float eps, float weight_decay, ms3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,17 @@ constexpr int ADAM_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adam_step_kernel(const int2 *__restrict__ chunks, float *const *__restrict__ p_ptrs,
                                                        const float *const *__restrict__ g_ptrs,
                                                        float *const *__restrict__ m_ptrs, float *const *__restrict__ v_ptrs,
-                                                       const long *__restrict__ sizes, float lr_over_bc1,
+                                                       const long *__restrict__ sizes,
+                                                       const float2 *__restrict__ coef, float lr_over_bc1,
                                                        float sqrt_bc2, float beta1, float beta2, float eps,
                                                        float weight_decay)
 {
     const int2 c = chunks[blockIdx.x];
+    if (coef) {     // per-tensor step counters: (lr / bias_correction1, sqrt(bias_correction2)) of THIS tensor
+        const float2 k = coef[c.x];
+        lr_over_bc1 = k.x;
+        sqrt_bc2 = k.y;
+    }
     float *p = p_ptrs[c.x];
     const float *g = g_ptrs[c.x];
     float *m = m_ptrs[c.x];
@@ -71,7 +77,22 @@ int ms3d_adam_step(const int *chunks, int n_chunks, void *const *p_ptrs, const v
     adam_step_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const int2 *>(chunks), reinterpret_cast<float *const *>(p_ptrs),
         reinterpret_cast<const float *const *>(g_ptrs), reinterpret_cast<float *const *>(m_ptrs),
-        reinterpret_cast<float *const *>(v_ptrs), sizes, lr_over_bc1, sqrt_bc2, beta1, beta2, eps, weight_decay);
+        reinterpret_cast<float *const *>(v_ptrs), sizes, nullptr, lr_over_bc1, sqrt_bc2, beta1, beta2, eps, weight_decay);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_adam_step_multi(const int *chunks, int n_chunks, void *const *p_ptrs, const void *const *g_ptrs,
+                         void *const *m_ptrs, void *const *v_ptrs, const long *sizes, const float *coef, float beta1,
+                         float beta2, float eps, float weight_decay, ms3d_stream_t stream)
+{
+    if (n_chunks <= 0) return 0;
+    if (!coef) return MS3D_E_UNSUPPORTED;
+    adam_step_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const int2 *>(chunks), reinterpret_cast<float *const *>(p_ptrs),
+        reinterpret_cast<const float *const *>(g_ptrs), reinterpret_cast<float *const *>(m_ptrs),
+        reinterpret_cast<float *const *>(v_ptrs), sizes, reinterpret_cast<const float2 *>(coef), 0.f, 1.f, beta1, beta2,
+        eps, weight_decay);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

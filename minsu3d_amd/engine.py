@@ -6,6 +6,7 @@ epochs over the train loader, cosine decay at every epoch end, validation + `epo
 Checkpoints use Lightning's top-level keys (`epoch`, `global_step`, `state_dict`, `optimizer_states`), so a reference
 `.ckpt` (README.md:146-151) loads through `load_checkpoint` as well: parameter names follow the reference modules
 (SURVEY Appendix D)."""
+import inspect
 import os
 
 import numpy as np
@@ -87,9 +88,16 @@ class Trainer:
             sync_buffers(model)          # every rank evaluates with rank 0's BatchNorm statistics
         model.eval()
         losses, acc, miou, preds, gts, boxes = [], [], [], [], [], []
+        loader = self.dm.val_dataloader()
+        sampler = getattr(loader, "batch_sampler", None)
+        # wrap-around repeats that pad the rank shards to equal length are run (every rank does the same number of
+        # steps) but not evaluated: a scan counts once in AP / mIoU
+        repeats = sampler.padded_positions() if hasattr(sampler, "padded_positions") else None
         with torch.no_grad():
-            for batch in self.dm.val_dataloader():
+            for k, batch in enumerate(loader):
                 out = model(batch)
+                if repeats is not None and repeats[k]:
+                    continue
                 losses.append(float(sum(model._loss(batch, out).values())))
                 sem_pred = out["semantic_scores"].max(1)[1]
                 acc.append(evaluate_semantic_accuracy(sem_pred, batch["sem_labels"], ignore_label=-1))
@@ -135,9 +143,9 @@ class Trainer:
         for epoch in range(start, max_epochs):
             model.current_epoch = epoch
             total, n = 0.0, 0
-            try:
-                loader = self.dm.train_dataloader(epoch)     # rank-sharded samplers reshuffle per epoch
-            except TypeError:
+            if "epoch" in inspect.signature(self.dm.train_dataloader).parameters:
+                loader = self.dm.train_dataloader(epoch=epoch)     # rank-sharded samplers reshuffle per epoch
+            else:
                 loader = self.dm.train_dataloader()
             batches = iter(loader)
             batch = next(batches, None)

@@ -1,10 +1,13 @@
 """Adam whose step is ONE library launch over all parameter tensors (`ms3d_adam_step`, csrc/optim.hip) -- the optimizer
 the reference builds through Hydra (`torch.optim.Adam`, config/model/base.yaml:23-28) with the same state
-(`step`, `exp_avg`, `exp_avg_sq` per parameter: checkpoints are interchangeable with torch.optim.Adam's) and the same
-arithmetic as torch's fused implementation.  Anything the kernel does not cover (amsgrad, maximize, capturable, sparse or
+(`step`, `exp_avg`, `exp_avg_sq` per parameter -- every parameter has its OWN step counter, started lazily with its first
+gradient, as in torch.optim.Adam: the ScoreNet / refinement branches get their first gradients after `prepare_epochs`
+and must start with bias corrections of step 1, not the backbone's; checkpoints are interchangeable with
+torch.optim.Adam's) and the same arithmetic as torch's fused implementation.  Anything the kernel does not cover (amsgrad, maximize, capturable, sparse or
 non-f32 parameters, CPU parameters) takes torch's own step."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -38,19 +41,48 @@ class Adam(torch.optim.Adam):
         plan = self._plans.get(gi)
         if plan is not None and plan["key"] == key:
             return plan
+        # the set of parameters with gradients changed (a branch switched on after `prepare_epochs`, a resumed state):
+        # hand the running counters back to the state dictionary, then read every parameter's OWN counter
+        self._flush()
         lib = get_backend().lib
         chunk = lib.ms3d_adam_chunk_elems()
         dev = params[0].device
         rows = []
         for t, p in enumerate(params):
             rows += [(t, c) for c in range(-(-p.numel() // chunk))]
-        plan = dict(key=key, lib=lib, n=len(params), n_chunks=len(rows),
+        steps = np.zeros(len(params), np.float64)
+        for t, p in enumerate(params):
+            st = self.state[p]
+            if len(st) == 0:                     # torch.optim.Adam's lazy state: a parameter's counter starts with its
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)          # first gradient (torch/optim/adam.py)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps[t] = float(st["step"])
+        host = [torch.empty((5, len(params)), dtype=torch.int64).pin_memory() for _ in range(_RING)]
+        plan = dict(key=key, lib=lib, n=len(params), n_chunks=len(rows), params=list(params), steps=steps,
                     chunks=torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).to(dev),
                     sizes=torch.tensor([p.numel() for p in params], dtype=torch.int64).to(dev),
-                    host=[torch.empty((4, len(params)), dtype=torch.int64).pin_memory() for _ in range(_RING)],
-                    dev=torch.zeros((4, len(params)), dtype=torch.int64, device=dev), last=None, turn=0)
+                    host=host, host_np=[h.numpy() for h in host],
+                    dev=torch.zeros((5, len(params)), dtype=torch.int64, device=dev), turn=0)
         self._plans[gi] = plan
         return plan
+
+    def _flush(self):
+        """the per-parameter step counters live in a host array between steps (250 scalar tensor increments per step
+        would cost the interpreter ~1 ms); this writes them back as torch.optim.Adam keeps them: ONE float32 scalar
+        tensor per parameter, no two parameters sharing a tensor"""
+        for plan in self._plans.values():
+            for p, t in zip(plan["params"], plan["steps"]):
+                self.state[p]["step"] = torch.tensor(float(t), dtype=torch.float32)
+        self._plans = {}
+
+    def state_dict(self):
+        self._flush()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._plans = {}
+        return super().load_state_dict(state_dict)
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -61,36 +93,32 @@ class Adam(torch.optim.Adam):
                 loss = closure()
         groups = [(gi, g, [p for p in g["params"] if p.grad is not None]) for gi, g in enumerate(self.param_groups)]
         if not all(self._eligible(g, ps) for _, g, ps in groups if ps):
-            return super().step() if closure is None else (super().step(), loss)[1]
+            self._flush()
+            super().step()
+            return loss
         for gi, group, params in groups:
             if not params:
                 continue
             beta1, beta2 = group["betas"]
-            # state, exactly torch.optim.Adam's; the step counter is ONE host tensor shared by the group's parameters
-            shared = None
-            for p in params:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if shared is None:
-                    shared = st["step"] if st["step"].device.type == "cpu" else st["step"].cpu()
-                st["step"] = shared
-            shared += 1
-            t = float(shared)
             plan = self._plan(gi, params)
-            host = plan["host"][plan["turn"]]
-            plan["turn"] = (plan["turn"] + 1) % _RING
-            ptrs = [[p.data_ptr() for p in params], [p.grad.data_ptr() for p in params],
-                    [self.state[p]["exp_avg"].data_ptr() for p in params],
-                    [self.state[p]["exp_avg_sq"].data_ptr() for p in params]]
-            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
-            plan["dev"].copy_(host, non_blocking=True)
+            plan["steps"] += 1.0
+            t = plan["steps"]
+            turn = plan["turn"]
+            plan["turn"] = (turn + 1) % _RING
+            hn = plan["host_np"][turn]
+            hn[0] = [p.data_ptr() for p in params]
+            hn[1] = [p.grad.data_ptr() for p in params]
+            hn[2] = [self.state[p]["exp_avg"].data_ptr() for p in params]
+            hn[3] = [self.state[p]["exp_avg_sq"].data_ptr() for p in params]
+            # per-tensor (lr / bias_correction1, sqrt(bias_correction2)) as two floats in the fifth row's 8-byte slots
+            coef = hn[4].view(np.float32).reshape(-1, 2)
+            coef[:, 0] = float(group["lr"]) / (1.0 - beta1 ** t)
+            coef[:, 1] = np.sqrt(1.0 - beta2 ** t)
+            plan["dev"].copy_(plan["host"][turn], non_blocking=True)
             d, n = plan["dev"].data_ptr(), plan["n"] * 8
-            _lib.check(plan["lib"].ms3d_adam_step(
+            _lib.check(plan["lib"].ms3d_adam_step_multi(
                 _lib.ptr(plan["chunks"]), plan["n_chunks"], C.c_void_p(d), C.c_void_p(d + n), C.c_void_p(d + 2 * n),
-                C.c_void_p(d + 3 * n), _lib.ptr(plan["sizes"]), C.c_float(float(group["lr"])), C.c_float(beta1),
-                C.c_float(beta2), C.c_float(group["eps"]), C.c_float(group["weight_decay"]),
-                C.c_double(1.0 - beta1 ** t), C.c_double(1.0 - beta2 ** t), _lib.stream_handle()), "ms3d_adam_step")
+                C.c_void_p(d + 3 * n), _lib.ptr(plan["sizes"]), C.c_void_p(d + 4 * n), C.c_float(beta1),
+                C.c_float(beta2), C.c_float(group["eps"]), C.c_float(group["weight_decay"]), _lib.stream_handle()),
+                "ms3d_adam_step_multi")
         return loss

@@ -69,9 +69,12 @@ class BalancedDistributedBatchSampler(torch.utils.data.Sampler):
     data_module.py:23-39) with the scenes of one step SIZE-MATCHED across ranks: a step lasts as long as its slowest
     rank, and scene sizes (hence ball-query / BFS / convolution work) spread over 2-3x in ScanNet.  Per epoch: one
     seeded permutation (identical on every rank) is cut into windows of world*batch*window_steps scenes; inside a window
-    the scenes are sorted by size and dealt out as consecutive batches -- batch j to rank j % world in step j // world --
-    so the ranks of a step hold neighbours in the size order; the steps of a window are then shuffled again.  Like
-    DistributedSampler the tail is padded by wrap-around so that every rank runs the same number of steps."""
+    the scenes are sorted by size and cut into steps of world*batch consecutive scenes, so the ranks of a step hold
+    neighbours in the size order; inside a step the scenes are dealt to the ranks in SERPENTINE order (0..W-1, W-1..0,
+    ...) starting at a rank that rotates with the step, so that no rank systematically receives the larger scenes of
+    every step; the steps of a window are then shuffled again.  Like DistributedSampler the tail is padded by
+    wrap-around so that every rank runs the same number of steps; `padded_positions()` tells which of THIS rank's
+    samples are such repeats (validation drops them before evaluating)."""
 
     def __init__(self, sizes, batch_size, rank=None, world_size=None, shuffle=True, seed=0, window_steps=8):
         self.sizes = [int(s) for s in sizes]
@@ -87,20 +90,39 @@ class BalancedDistributedBatchSampler(torch.utils.data.Sampler):
         per_step = self.batch_size * self.world
         return (len(self.sizes) + per_step - 1) // per_step
 
-    def __iter__(self):
+    def _deal(self, step_scenes, step_index):
+        """this rank's share of one step's scenes (ascending size): serpentine over the ranks, rotated per step"""
+        W = self.world
+        mine = []
+        for j, scene in enumerate(step_scenes):
+            lap, pos = divmod(j, W)
+            r = pos if lap % 2 == 0 else W - 1 - pos
+            if (r + step_index) % W == self.rank:
+                mine.append(scene)
+        return mine
+
+    def _steps(self):
         n = len(self.sizes)
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         order = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
         per_step = self.batch_size * self.world
         total = len(self) * per_step
         order = (order * (total // max(n, 1) + 1))[:total]               # wrap-around padding
+        order = [(i, k >= n) for k, i in enumerate(order)]                 # (scene, is a padding repeat)
         win = per_step * self.window_steps
         steps = []
         for w0 in range(0, total, win):
-            chunk = sorted(order[w0:w0 + win], key=lambda i: (self.sizes[i], i))
+            chunk = sorted(order[w0:w0 + win], key=lambda e: (self.sizes[e[0]], e[0], e[1]))
             wsteps = [chunk[s:s + per_step] for s in range(0, len(chunk), per_step)]
             if self.shuffle:
                 wsteps = [wsteps[i] for i in torch.randperm(len(wsteps), generator=g).tolist()]
             steps.extend(wsteps)
-        for st in steps:                                                   # scenes of a step, ascending size:
-            yield st[self.rank::self.world]                                # rank r takes every world-th one
+        return [self._deal(st, k) for k, st in enumerate(steps)]
+
+    def __iter__(self):
+        for st in self._steps():
+            yield [scene for scene, _ in st]
+
+    def padded_positions(self):
+        """flags, in iteration order over this rank's samples, of the wrap-around repeats"""
+        return [pad for st in self._steps() for _, pad in st]

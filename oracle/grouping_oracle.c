@@ -329,11 +329,58 @@ void orc_get_mask_label(int I, int P, int ignored_label, float iou_thr, const in
  * Outputs have capacity n rows / n+1 offsets.  Returns nCluster.                     */
 #define HA_MAX_FRAG 1024
 #define HA_MAX_PTS 8192
-int orc_hierarchical_aggregation(const int16_t *sem, const float *coord_shift,
-                                 const uint8_t *batch_idxs, const int *ball_idx,
-                                 const int *start_len, int n, int using_set_aggr,
-                                 const float *point_num_avg, const float *radius_avg,
-                                 int *cluster_idxs, int *cluster_offsets, int *sum_out)
+/* the four lists + centre rows (x, y, z, class, scene) hierarchical_aggregation.cpp:133-175 hands back: all fragments
+ * (size < 0.3 avg), kept fragments (>= 0.05 avg), primaries, primaries with their absorbed fragments (set aggregation) */
+typedef struct {
+    int *frag_idx, *frag_off; float *frag_ctr; int n_frag, frag_sum;
+    int *kept_idx, *kept_off; float *kept_ctr; int n_kept, kept_sum;
+    int *prim_idx, *prim_off; float *prim_ctr; int n_prim, prim_sum;
+    int *post_idx, *post_off; int n_post, post_sum;
+} orc_ha_parts;
+
+/* append the components with `kind & bit` (ascending seed) to a (cluster id, point) list; with `absorb_to`, a primary
+ * is followed by the fragments absorbed into it in ascending fragment index under the caps of .cu:80-90 */
+static void ha_emit(int ncc, const char *kind, int bit, const int *all_idx, const int *all_off, const int *absorb_to,
+                    int unused, int *out_idx, int *out_off, int *ncl_io, int *sum_io, float *out_ctr, const float *ctr)
+{
+    (void)unused;
+    int ncl = *ncl_io, sum = *sum_io;
+    for (int c = 0; c < ncc; c++) {
+        if (!(kind[c] & bit)) continue;
+        for (int q = all_off[c]; q < all_off[c + 1]; q++) {
+            out_idx[sum * 2 + 0] = ncl;
+            out_idx[sum * 2 + 1] = all_idx[q * 2 + 1];
+            sum++;
+        }
+        if (absorb_to) {
+            int nfrag = 0, npts = 0;
+            for (int f = 0; f < ncc; f++) {
+                if (absorb_to[f] != c) continue;
+                if (nfrag >= HA_MAX_FRAG) break;
+                nfrag++;
+                for (int q = all_off[f]; q < all_off[f + 1]; q++) {
+                    if (npts < HA_MAX_PTS) {
+                        out_idx[sum * 2 + 0] = ncl;
+                        out_idx[sum * 2 + 1] = all_idx[q * 2 + 1];
+                        sum++;
+                        npts++;
+                    }
+                }
+            }
+        }
+        if (out_ctr)
+            for (int k = 0; k < 5; k++) out_ctr[ncl * 5 + k] = ctr[c * 5 + k];
+        out_off[++ncl] = sum;
+    }
+    *ncl_io = ncl;
+    *sum_io = sum;
+}
+
+static int ha_run(const int16_t *sem, const float *coord_shift,
+                  const uint8_t *batch_idxs, const int *ball_idx,
+                  const int *start_len, int n, int using_set_aggr,
+                  const float *point_num_avg, const float *radius_avg,
+                  int *cluster_idxs, int *cluster_offsets, int *sum_out, orc_ha_parts *parts)
 {
     int *all_idx = (int *)malloc(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1));
     int *all_off = (int *)malloc(sizeof(int) * (size_t)(n + 1));
@@ -395,42 +442,48 @@ int orc_hierarchical_aggregation(const int16_t *sem, const float *coord_shift,
     /* emit: kept fragments first, then primaries (+absorbed), hais_ops.py:55-73 */
     int ncl = 0, sum = 0;
     cluster_offsets[0] = 0;
-    for (int c = 0; c < ncc; c++) {
-        if (!(kind[c] & 2)) continue;
-        for (int q = all_off[c]; q < all_off[c + 1]; q++) {
-            cluster_idxs[sum * 2 + 0] = ncl;
-            cluster_idxs[sum * 2 + 1] = all_idx[q * 2 + 1];
-            sum++;
-        }
-        cluster_offsets[++ncl] = sum;
-    }
-    for (int c = 0; c < ncc; c++) {
-        if (!(kind[c] & 4)) continue;
-        for (int q = all_off[c]; q < all_off[c + 1]; q++) {
-            cluster_idxs[sum * 2 + 0] = ncl;
-            cluster_idxs[sum * 2 + 1] = all_idx[q * 2 + 1];
-            sum++;
-        }
-        if (using_set_aggr) { /* .cu:80-90 caps */
-            int nfrag = 0, npts = 0;
-            for (int f = 0; f < ncc; f++) {
-                if (absorb_to[f] != c) continue;
-                if (nfrag >= HA_MAX_FRAG) break;
-                nfrag++;
-                for (int q = all_off[f]; q < all_off[f + 1]; q++) {
-                    if (npts < HA_MAX_PTS) {
-                        cluster_idxs[sum * 2 + 0] = ncl;
-                        cluster_idxs[sum * 2 + 1] = all_idx[q * 2 + 1];
-                        sum++;
-                        npts++;
-                    }
-                }
-            }
-        }
-        cluster_offsets[++ncl] = sum;
+    ha_emit(ncc, kind, 2, all_idx, all_off, NULL, 0, cluster_idxs, cluster_offsets, &ncl, &sum, NULL, ctr);
+    ha_emit(ncc, kind, 4, all_idx, all_off, using_set_aggr ? absorb_to : NULL, 0, cluster_idxs, cluster_offsets,
+            &ncl, &sum, NULL, ctr);
+    if (parts) { /* the lists hierarchical_aggregation.cpp:133-175 leaves in the caller's tensors, ids from 0 each */
+        int c0 = 0, s0 = 0;
+        parts->frag_off[0] = 0;
+        ha_emit(ncc, kind, 1, all_idx, all_off, NULL, 0, parts->frag_idx, parts->frag_off, &c0, &s0, parts->frag_ctr, ctr);
+        parts->n_frag = c0; parts->frag_sum = s0;
+        c0 = s0 = 0; parts->kept_off[0] = 0;
+        ha_emit(ncc, kind, 2, all_idx, all_off, NULL, 0, parts->kept_idx, parts->kept_off, &c0, &s0, parts->kept_ctr, ctr);
+        parts->n_kept = c0; parts->kept_sum = s0;
+        c0 = s0 = 0; parts->prim_off[0] = 0;
+        ha_emit(ncc, kind, 4, all_idx, all_off, NULL, 0, parts->prim_idx, parts->prim_off, &c0, &s0, parts->prim_ctr, ctr);
+        parts->n_prim = c0; parts->prim_sum = s0;
+        c0 = s0 = 0; parts->post_off[0] = 0;
+        if (using_set_aggr)
+            ha_emit(ncc, kind, 4, all_idx, all_off, absorb_to, 0, parts->post_idx, parts->post_off, &c0, &s0, NULL, ctr);
+        parts->n_post = c0; parts->post_sum = s0;
     }
     free(all_idx); free(all_off); free(acc); free(lab); free(bat); free(kind); free(ctr);
     free(absorb_to);
     *sum_out = sum;
     return ncl;
+}
+
+int orc_hierarchical_aggregation(const int16_t *sem, const float *coord_shift,
+                                 const uint8_t *batch_idxs, const int *ball_idx,
+                                 const int *start_len, int n, int using_set_aggr,
+                                 const float *point_num_avg, const float *radius_avg,
+                                 int *cluster_idxs, int *cluster_offsets, int *sum_out)
+{
+    return ha_run(sem, coord_shift, batch_idxs, ball_idx, start_len, n, using_set_aggr, point_num_avg, radius_avg,
+                  cluster_idxs, cluster_offsets, sum_out, NULL);
+}
+
+/* as above, and the raw lists in `parts` (buffers: *_idx 2*2n ints, *_off n+1 ints, *_ctr 5n floats; post_idx 2*2n) */
+int orc_hierarchical_aggregation_parts(const int16_t *sem, const float *coord_shift,
+                                       const uint8_t *batch_idxs, const int *ball_idx,
+                                       const int *start_len, int n, int using_set_aggr,
+                                       const float *point_num_avg, const float *radius_avg,
+                                       int *cluster_idxs, int *cluster_offsets, int *sum_out, orc_ha_parts *parts)
+{
+    return ha_run(sem, coord_shift, batch_idxs, ball_idx, start_len, n, using_set_aggr, point_num_avg, radius_avg,
+                  cluster_idxs, cluster_offsets, sum_out, parts);
 }

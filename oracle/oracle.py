@@ -107,11 +107,16 @@ def sg_bfs_cluster(class_numpoint_mean, ball_idx, start_len, threshold, class_id
 
 
 def hierarchical_aggregation(sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr, point_num_avg,
-                             radius_avg, ignored_label=-1, use_ref=False):
+                             radius_avg, ignored_label=-1, use_ref=False, parts=False):
+    """-> (cluster_idxs [S,2], cluster_offsets) after the wrapper's merge (hais_ops.py:55-73); with parts=True the raw
+    lists hierarchical_aggregation.cpp:133-175 leaves in the caller's tensors instead: a dict of
+    'fragment' / 'kept' / 'primary' -> (idxs [S,2], offsets, centres [P,5]) and 'post' -> (idxs, offsets)"""
     sem = _c(sem, np.int16); cs = _c(coord_shift, np.float32); bi = _c(ball_idx, np.int32)
     sl = _c(start_len, np.int32); b = _c(batch_idxs, np.uint8)
     pna = _c(point_num_avg, np.float32); ra = _c(radius_avg, np.float32)
     n = sl.shape[0]
+    if parts:
+        return _ha_parts(sem, cs, b, bi, sl, n, using_set_aggr, pna, ra)
     if not use_ref:
         oi, oo, s = _bfs_out(n, 2 * n)
         nc = lib().orc_hierarchical_aggregation(_p(sem, i16p), _p(cs, f32p), _p(b, u8p), _p(bi, i32p),
@@ -134,6 +139,32 @@ def hierarchical_aggregation(sem, coord_shift, ball_idx, start_len, batch_idxs, 
         ki = np.concatenate([ki, pi], 0)
         ko = np.concatenate([ko, po[1:]])
     return ki, ko
+
+
+class _HaParts(C.Structure):
+    _fields_ = [(k, t) for grp in ("frag", "kept", "prim") for k, t in
+                ((grp + "_idx", i32p), (grp + "_off", i32p), (grp + "_ctr", f32p), ("n_" + grp, C.c_int),
+                 (grp + "_sum", C.c_int))] + \
+               [("post_idx", i32p), ("post_off", i32p), ("n_post", C.c_int), ("post_sum", C.c_int)]
+
+
+def _ha_parts(sem, cs, b, bi, sl, n, using_set_aggr, pna, ra):
+    oi, oo, s = _bfs_out(n, 2 * n)
+    bufs, P = {}, _HaParts()
+    for grp in ("frag", "kept", "prim", "post"):
+        bufs[grp] = (np.zeros((2 * max(n, 1), 2), np.int32), np.zeros(n + 1, np.int32), np.zeros((max(n, 1), 5), np.float32))
+        setattr(P, grp + "_idx", _p(bufs[grp][0], i32p)); setattr(P, grp + "_off", _p(bufs[grp][1], i32p))
+        if grp != "post":
+            setattr(P, grp + "_ctr", _p(bufs[grp][2], f32p))
+    lib().orc_hierarchical_aggregation_parts(_p(sem, i16p), _p(cs, f32p), _p(b, u8p), _p(bi, i32p), _p(sl, i32p), n,
+                                             int(bool(using_set_aggr)), _p(pna, f32p), _p(ra, f32p), _p(oi, i32p),
+                                             _p(oo, i32p), C.byref(s), C.byref(P))
+    out = {}
+    for grp, name in (("frag", "fragment"), ("kept", "kept"), ("prim", "primary"), ("post", "post")):
+        k, m = getattr(P, "n_" + grp), getattr(P, grp + "_sum")
+        out[name] = (bufs[grp][0][:m].copy(), bufs[grp][1][:k + 1].copy()) + \
+            ((bufs[grp][2][:k].copy(),) if grp != "post" else ())
+    return out
 
 
 def _seg(name, inp, offsets):

@@ -1,9 +1,11 @@
 """CPU restatement of the reference's instance post-processing -- TEST INFRASTRUCTURE ONLY.
 
 Follows minsu3d/model/pointgroup.py:177-265 (_get_nms_instances, _get_pred_instances), hais.py:210-247 and
-softgroup.py:269-313 with dense [P, N] boolean masks, exactly the formulation the reference uses.  PARITY UNPINNED
-against the reference itself: those methods live in LightningModules that cannot be imported here (pytorch_lightning /
-MinkowskiEngine absent); the pieces they call that CAN be imported (rle_encode) are pinned in tests/golden."""
+softgroup.py:269-313 with dense [P, N] boolean masks, exactly the formulation the reference uses.  PINNED: the reference's
+own methods were run on seeded proposal sets in the build container (tests/golden/make_golden_model.py registers
+container-only stand-ins for pytorch_lightning / hydra and this repository's MinkowskiEngine / COMMON_OPS modules so that
+minsu3d.model imports) and their instance lists are the fixtures tests/golden/model_tree.json + model_cases.npz;
+tests/test_reference_pins_cpu.py::test_postprocess_oracle_is_pinned compares this file with them."""
 import numpy as np
 
 

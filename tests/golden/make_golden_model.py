@@ -1,0 +1,255 @@
+"""Golden vectors from the reference's own Python model code -- runs ONLY in the build container
+(`python tests/golden/make_golden_model.py`), where /root/reference exists.  Nothing of the reference travels: the
+script writes DATA (key names, shapes, numbers) to tests/golden/model_tree.json and tests/golden/model_cases.npz.
+
+The reference's model files import three packages this image does not have.  They are stood in for HERE, in this
+process only, by the minimum the model code touches:
+
+  pytorch_lightning   LightningModule = nn.Module + save_hyperparameters() / hparams / current_epoch / device / log
+  hydra               hydra.utils.instantiate (never called by what is exercised below)
+  MinkowskiEngine,    minsu3d_amd.dropin.install(): the implementation under test behind the reference's import names;
+  COMMON_OPS          the CPU test-double backend (oracle/) answers the operators, there is no GPU here
+
+What is captured (reference file:line):
+  (i)   state_dict key names, shapes and dtypes of the reference's PointGroup / HAIS / SoftGroup module trees built
+        from the reference's own YAML (model/module/common.py:21-95, backbone.py:8-34, tiny_unet.py:7-16,
+        pointgroup.py:13-21, hais.py:12-26, softgroup.py:11-30);
+  (ii)  the reference's Backbone.forward / TinyUnet.forward COMPOSITION (backbone.py:36-43, common.py:43-49,85-95) run
+        on a small seeded scene with seeded parameters -> semantic scores, offsets, point features;
+  (iii) _get_pred_instances / _get_nms_instances of the three models on seeded proposal sets
+        (pointgroup.py:177-265, hais.py:210-247, softgroup.py:269-313) with the reference's thresholds;
+  (iv)  GeneralModel._loss, PTOffsetLoss, get_segmented_scores on seeded inputs (general_model.py:36-50,196-213,
+        loss/pt_offset_loss.py:11-38).
+"""
+import inspect
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+# ------------------------------------------------------------------------------------------------ stand-ins
+def install_standins():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.current_epoch = 0
+
+        def save_hyperparameters(self):
+            frame = inspect.currentframe().f_back
+            args = {k: v for k, v in frame.f_locals.items() if k not in ("self", "__class__")}
+            self.hparams = types.SimpleNamespace(**args)
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        def log(self, *a, **k):
+            pass
+
+        def print(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    hydra = types.ModuleType("hydra")
+    hydra.utils = types.ModuleType("hydra.utils")
+
+    def instantiate(cfg, **kw):
+        d = dict(cfg)
+        mod, _, name = d.pop("_target_").rpartition(".")
+        return getattr(__import__(mod, fromlist=[name]), name)(**d, **kw)
+
+    hydra.utils.instantiate = instantiate
+    hydra.main = lambda **k: (lambda f: f)
+    sys.modules["hydra"] = hydra
+    sys.modules["hydra.utils"] = hydra.utils
+    import minsu3d_amd.dropin as dropin
+    dropin.install()
+    from minsu3d_amd import backend
+    from oracle.oracle_backend import OracleBackend
+    backend.set_backend(OracleBackend())
+    sys.path.insert(0, REF)
+
+
+# ------------------------------------------------------------------------------------------------ reference YAML
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _merge(a, b):
+    for k, v in b.items():
+        if isinstance(v, dict) and isinstance(a.get(k), dict):
+            _merge(a[k], v)
+        else:
+            a[k] = v
+    return a
+
+
+def _group(group, name):
+    with open(os.path.join(REF, "config", group, name + ".yaml")) as f:
+        d = yaml.safe_load(f)
+    out = {}
+    for base in d.pop("defaults", []):
+        _merge(out, _group(group, base))
+    return _merge(out, d)
+
+
+def reference_cfg(model, data="scannetv2", **net):
+    """the reference's YAML tree composed the way Hydra composes it (defaults first, then the file itself)"""
+    with open(os.path.join(REF, "config", "config.yaml")) as f:
+        top = yaml.safe_load(f)
+    top.pop("hydra", None), top.pop("defaults", None)
+    top["data"], top["model"] = _group("data", data), _group("model", model)
+    top["model"]["network"].update(net)
+    top["project_root_path"] = "/tmp"
+    pat = re.compile(r"\$\{([^}]+)\}")
+
+    def look(path):
+        cur = top
+        for p in path.split("."):
+            cur = cur[p]
+        return cur
+
+    def res(v):
+        if isinstance(v, str):
+            for _ in range(8):
+                m = pat.search(v)
+                if not m:
+                    break
+                val = look(m.group(1))
+                v = val if m.group(0) == v else v.replace(m.group(0), str(val))
+                if not isinstance(v, str):
+                    break
+            return v
+        if isinstance(v, dict):
+            return Cfg({k: res(x) for k, x in v.items()})
+        if isinstance(v, list):
+            return [res(x) for x in v]
+        return v
+
+    return res(top)
+
+
+def main():
+    install_standins()
+    import minsu3d.model as RM                       # the reference's package, on the stand-ins
+    from minsu3d.model.general_model import GeneralModel, get_segmented_scores
+    from minsu3d.loss.pt_offset_loss import PTOffsetLoss
+    from minsu3d.model.module import Backbone, TinyUnet
+    import MinkowskiEngine as ME
+    from postprocess_cases import make_case, make_softgroup_scores, mask_digest
+    from model_cases import loss_inputs, seeded_fill, small_scene, tiny_input
+
+    tree, arrays = {}, {}
+    # (i) module trees -------------------------------------------------------------------------------------
+    for name, cls in (("pointgroup", RM.PointGroup), ("hais", RM.HAIS), ("softgroup", RM.SoftGroup)):
+        model = cls(reference_cfg(name))
+        tree[name] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+        tree[name + "_trainable"] = [k for k, _ in model.named_parameters()]
+        tree[name + "_hparams"] = {"m": model.hparams.cfg.model.network.m,
+                                   "lr": model.hparams.cfg.model.optimizer.lr,
+                                   "max_epochs": model.hparams.cfg.model.trainer.max_epochs,
+                                   "decay_start_epoch": model.hparams.cfg.model.lr_decay.decay_start_epoch,
+                                   "prepare_epochs": model.hparams.cfg.model.network.prepare_epochs}
+
+    # (ii) forward composition (m = 4 keeps the fixture small; the topology is the 7-level one) -----------------
+    for mode in ("train", "eval"):
+        torch.manual_seed(0)
+        bb = Backbone(input_channel=6, output_channel=4, block_channels=[1, 2, 3, 4, 5, 6, 7], block_reps=2,
+                      sem_classes=20)
+        seeded_fill(bb, 11)
+        bb.train(mode == "train")
+        batch = small_scene(5)
+        with torch.no_grad():
+            out = bb(batch["voxel_features"], batch["voxel_xyz"], batch["voxel_point_map"])
+        for k in ("point_features", "semantic_scores", "point_offsets"):
+            arrays[f"backbone_{mode}_{k}"] = out[k].numpy()
+        if mode == "train":
+            sd = bb.state_dict()
+            k = "unet.1.blocks.block0.conv_branch.0.bn."
+            arrays["backbone_train_running_mean"] = sd[k + "running_mean"].numpy()
+            arrays["backbone_train_running_var"] = sd[k + "running_var"].numpy()
+        tu = TinyUnet(4)
+        seeded_fill(tu, 12)
+        tu.train(mode == "train")
+        coords, feats = tiny_input()
+        with torch.no_grad():
+            arrays[f"tiny_{mode}_out"] = tu(ME.SparseTensor(features=feats, coordinates=coords)).features.numpy()
+
+    # (iii) instance post-processing --------------------------------------------------------------------------
+    def dump_instances(tag, insts):
+        # (the run-length strings of a few hundred instances are megabytes: their digest + point count is kept)
+        tree[tag] = [{"scan_id": d["scan_id"], "label_id": int(d["label_id"]), "pred_mask": mask_digest(d["pred_mask"])}
+                     for d in insts]
+        arrays[tag + "_conf"] = np.array([d["conf"] for d in insts], np.float32)
+        arrays[tag + "_bbox"] = np.array([d["pred_bbox"] for d in insts], np.float32).reshape(-1, 6)
+
+    for seed in (0, 1, 2):
+        c = make_case(seed)
+        t = lambda a: torch.from_numpy(a)
+        cfg = reference_cfg("pointgroup")
+        me = types.SimpleNamespace(hparams=types.SimpleNamespace(cfg=cfg))
+        me._get_nms_instances = types.MethodType(RM.PointGroup._get_nms_instances, me)
+        insts = RM.PointGroup._get_pred_instances(me, "scene%04d_00" % seed, c["xyz"], t(c["scores"]).view(-1, 1),
+                                                  t(c["proposals_idx"]).long(), c["P"], t(c["sem"]), 2)
+        dump_instances(f"pg_inst{seed}", insts)
+        cfg = reference_cfg("hais")
+        me = types.SimpleNamespace(hparams=types.SimpleNamespace(cfg=cfg))
+        insts = RM.HAIS._get_pred_instances(me, "scene%04d_00" % seed, c["xyz"], t(c["scores"]).view(-1, 1),
+                                            t(c["proposals_idx"]).long(), c["P"], t(c["mask_scores"]).view(-1, 1),
+                                            t(c["sem"]), 2)
+        dump_instances(f"hais_inst{seed}", insts)
+        cfg = reference_cfg("softgroup")
+        n_cls = cfg.data.classes - len(cfg.data.ignore_classes)
+        cls_scores, iou_scores, mask_scores = make_softgroup_scores(seed, c["P"], c["proposals_idx"].shape[0], n_cls)
+        me = types.SimpleNamespace(hparams=types.SimpleNamespace(cfg=cfg), instance_classes=n_cls)
+        insts = RM.SoftGroup._get_pred_instances(me, "scene%04d_00" % seed, c["xyz"], t(c["proposals_idx"]).long(),
+                                                 c["n"], t(cls_scores), t(iou_scores), t(mask_scores), 2)
+        dump_instances(f"sg_inst{seed}", insts)
+    tree["thresholds"] = {"pg": dict(reference_cfg("pointgroup").model.network.test),
+                          "hais": dict(reference_cfg("hais").model.network.test),
+                          "sg": dict(reference_cfg("softgroup").model.network.test_cfg)}
+
+    # (iv) losses -----------------------------------------------------------------------------------------------
+    li = loss_inputs()
+    sem_scores, labels, inst, xyz, centre, offs = (li[k] for k in ("sem_scores", "labels", "inst", "xyz", "centre", "offs"))
+    n = labels.numel()
+    me = types.SimpleNamespace()
+    losses = GeneralModel._loss(me, {"sem_labels": labels, "instance_center_xyz": centre, "point_xyz": xyz,
+                                     "instance_ids": inst},
+                                {"semantic_scores": sem_scores, "point_offsets": offs})
+    arrays["loss_inputs_sem_scores"], arrays["loss_inputs_labels"] = sem_scores.numpy(), labels.numpy()
+    arrays["loss_inputs_inst"], arrays["loss_inputs_xyz"] = inst.numpy(), xyz.numpy()
+    arrays["loss_inputs_centre"], arrays["loss_inputs_offs"] = centre.numpy(), offs.numpy()
+    arrays["loss_values"] = np.array([float(losses[k]) for k in ("semantic_loss", "offset_norm_loss", "offset_dir_loss")],
+                                     np.float64)
+    empty = PTOffsetLoss()(offs, centre - xyz, valid_mask=torch.zeros(n, dtype=torch.bool))
+    tree["offset_loss_no_valid_points"] = [float(empty[0]), float(empty[1])]
+    s = li["seg"]
+    arrays["seg_scores_in"] = s.numpy()
+    arrays["seg_scores_pg"] = get_segmented_scores(s, 0.75, 0.25).numpy()
+    arrays["seg_scores_default"] = get_segmented_scores(s).numpy()
+
+    with open(os.path.join(HERE, "model_tree.json"), "w") as f:
+        json.dump(tree, f, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **arrays)
+    print("wrote model_tree.json (%d entries), model_cases.npz (%d arrays)" % (len(tree), len(arrays)))
+
+
+if __name__ == "__main__":
+    main()

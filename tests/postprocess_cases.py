@@ -38,3 +38,20 @@ def assert_same_instances(got, want):
         assert g["pred_mask"] == w["pred_mask"]
         assert np.float32(g["conf"]) == np.float32(w["conf"]) or abs(float(g["conf"]) - float(w["conf"])) < 1e-6
         assert np.array_equal(np.asarray(g["pred_bbox"], np.float32), np.asarray(w["pred_bbox"], np.float32))
+
+
+def make_softgroup_scores(seed, P, S, n_cls):
+    """per-class heads of SoftGroup's refinement for the proposals of make_case(seed): classification logits [P, C+1],
+    IoU scores [P, C+1], per-point mask scores [S, C+1]"""
+    rng = np.random.default_rng(100 + seed)
+    cls_scores = rng.normal(0, 2.5, (P, n_cls + 1)).astype(np.float32)
+    iou_scores = rng.normal(0.6, 0.5, (P, n_cls + 1)).astype(np.float32)
+    mask_scores = rng.normal(0.0, 1.0, (S, n_cls + 1)).astype(np.float32)
+    return cls_scores, iou_scores, mask_scores
+
+
+def mask_digest(rle):
+    """{'length', 'counts'} run-length mask -> (length, point count, sha1 of the counts string)"""
+    import hashlib
+    runs = [int(x) for x in rle["counts"].split()]
+    return [int(rle["length"]), int(sum(runs[1::2])), hashlib.sha1(rle["counts"].encode()).hexdigest()]

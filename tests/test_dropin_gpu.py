@@ -28,26 +28,27 @@ def _scene(seed, n=12000, B=2):
     return xyz, b, bo, sem
 
 
-def _ballquery(OPS, coords, batch_idxs, batch_offsets, radius, meanActive):
-    """functions/common_ops.py:11-47 (BallQueryBatchP.forward), verbatim control flow"""
+def _ballquery(OPS, coords, batch_idxs, batch_offsets, radius, capacity):
+    """the caller side of COMMON_OPS.ballquery_batch_p (functions/common_ops.py:11-47): outputs sized by a guessed mean
+    list length; the call reports the true total and is repeated with a sufficient size when the guess was too small"""
     n = coords.size(0)
-    assert coords.is_contiguous() and coords.is_cuda
-    while True:
-        idx = torch.zeros(n * meanActive, dtype=torch.int32, device="cuda")
+    for attempt in range(3):
+        idx = torch.zeros(n * capacity, dtype=torch.int32, device="cuda")
         start_len = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
-        nActive = OPS.ballquery_batch_p(coords, batch_idxs, batch_offsets, idx, start_len, n, meanActive, radius)
-        if nActive <= n * meanActive:
-            break
-        meanActive = int(nActive // n + 1)
-    return idx[:nActive], start_len
+        total = OPS.ballquery_batch_p(coords, batch_idxs, batch_offsets, idx, start_len, n, capacity, radius)
+        if total <= idx.numel():
+            return idx[:total], start_len, attempt
+        capacity = total // n + 1
+    raise AssertionError("ball query did not fit after resizing")
 
 
 def test_pointgroup_call_sequence(OPS, oracle):
     """model/pointgroup.py:43-55: ball query on the GPU, `.cpu()`, pg_bfs_cluster on CPU tensors with empty_like outputs
     (functions/pointgroup_ops.py:8-29)"""
     xyz, b, bo, sem = _scene(0)
-    idx, start_len = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
-                                torch.from_numpy(bo).cuda(), 0.04, 2)     # meanActive too small: exercises the retry
+    idx, start_len, retries = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
+                                         torch.from_numpy(bo).cuda(), 0.04, 2)
+    assert retries == 1                                                    # meanActive = 2 is too small: one resize
     widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
     assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(start_len.cpu().numpy(), wsl)
     semantic_label = torch.from_numpy(sem)                                 # CPU, as semantic_preds_cpu
@@ -84,63 +85,39 @@ def test_softgroup_call_sequence(OPS, oracle):
 
 @pytest.mark.parametrize("using_set_aggr", [False, True])
 def test_hais_call_sequence(OPS, oracle, using_set_aggr):
-    """functions/hais_ops.py:22-73 (HierarchicalAggregation.forward) on CPU tensors, post-processing included"""
+    """COMMON_OPS.hierarchical_aggregation on CPU tensors with the 11 caller-provided outputs (the wrapper's calling
+    convention, functions/hais_ops.py:22-53): every list the reference leaves in them (hierarchical_aggregation.cpp:133-175)
+    against the oracle's raw lists"""
     xyz, b, bo, sem = _scene(2)
     widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.04)
-    semantic_label, coord_shift = torch.from_numpy(sem), torch.from_numpy(xyz)
-    ball_query_idxs, start_len, batch_idxs = torch.from_numpy(widx), torch.from_numpy(wsl), torch.from_numpy(b)
     point_num_avg = [100.0, 200.0, 400.0, 800.0, 1600.0]
     radius_avg = [0.1, 0.2, 0.3, 0.5, 0.8]
-    N = start_len.size(0)
-    fragment_idxs = torch.empty_like(semantic_label, dtype=torch.int32)
-    fragment_offsets = torch.empty_like(semantic_label, dtype=torch.int32)
-    fragment_centers = coord_shift.new()
-    cluster_idxs_kept = torch.empty_like(semantic_label, dtype=torch.int32)
-    cluster_offsets_kept = torch.empty_like(semantic_label, dtype=torch.int32)
-    cluster_centers_kept = coord_shift.new()
-    primary_idxs = torch.empty_like(semantic_label, dtype=torch.int32)
-    primary_offsets = torch.empty_like(semantic_label, dtype=torch.int32)
-    primary_centers = coord_shift.new()
-    primary_idxs_post = torch.empty_like(semantic_label, dtype=torch.int32)
-    primary_offsets_post = torch.empty_like(semantic_label, dtype=torch.int32)
-    using_set_aggr_ = int(using_set_aggr)
-    OPS.hierarchical_aggregation(semantic_label, coord_shift, batch_idxs, ball_query_idxs, start_len,
-                                 fragment_idxs, fragment_offsets, fragment_centers,
-                                 cluster_idxs_kept, cluster_offsets_kept, cluster_centers_kept,
-                                 primary_idxs, primary_offsets, primary_centers,
-                                 primary_idxs_post, primary_offsets_post,
-                                 torch.tensor(point_num_avg, dtype=torch.float32, device="cpu"),
-                                 torch.tensor(radius_avg, dtype=torch.float32, device="cpu"),
-                                 N, using_set_aggr_, -1)
-    assert cluster_centers_kept.shape == (cluster_offsets_kept.numel() - 1, 5)
-    assert primary_centers.shape == (primary_offsets.numel() - 1, 5)
-    n_prim_raw_rows = primary_idxs.shape[0]
-    if using_set_aggr_ != 0:
-        assert fragment_centers.shape == (fragment_offsets.numel() - 1, 5)
-        assert primary_idxs_post.shape[0] == fragment_idxs.shape[0] + n_prim_raw_rows     # zero tail, .cpp:166
-        assert not primary_idxs_post[int(primary_offsets_post[-1]):].any()
-        primary_idxs_post = primary_idxs_post[:primary_offsets_post[-1]]
-        primary_idxs = primary_idxs_post
-        primary_offsets = primary_offsets_post
-    cluster_idxs, cluster_offsets = cluster_idxs_kept, cluster_offsets_kept
-    if primary_idxs.shape[0] != 0:
-        primary_idxs[:, 0] += (cluster_offsets.size(0) - 1)
-        primary_offsets += cluster_offsets[-1]
-        cluster_idxs = torch.cat((cluster_idxs, primary_idxs), dim=0)
-        cluster_offsets = torch.cat((cluster_offsets, primary_offsets[1:]))
-    want = oracle.hierarchical_aggregation(sem, xyz, widx, wsl, b, using_set_aggr, point_num_avg, radius_avg)
-    assert np.array_equal(cluster_offsets.numpy(), want[1])
-    assert np.array_equal(cluster_idxs.numpy().reshape(-1, 2), want[0].reshape(-1, 2))
-    assert (np.diff(want[1]) > 0).all() and len(want[1]) > 3          # the case is not degenerate
-    # centres: serial f32 sums in BFS order (find_cc's accum_x/y/z), class and scene of the seed
-    ck = cluster_centers_kept.numpy()
-    for c in range(min(ck.shape[0], 20)):
-        members = cluster_idxs_kept[cluster_offsets_kept[c]:cluster_offsets_kept[c + 1], 1].numpy()
-        acc = np.zeros(3, np.float32)
-        for m in members:
-            acc += xyz[m]
-        assert np.array_equal(ck[c, :3], acc / np.float32(len(members)))
-        assert ck[c, 3] == sem[members[0]] and ck[c, 4] == b[members[0]]
+    out = {}
+    for group in ("fragment", "kept", "primary", "post"):           # (idxs, offsets[, centres]) per list, all empty
+        out[group] = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
+        if group != "post":
+            out[group].append(torch.empty(0, dtype=torch.float32))
+    OPS.hierarchical_aggregation(torch.from_numpy(sem), torch.from_numpy(xyz), torch.from_numpy(b), torch.from_numpy(widx),
+                                 torch.from_numpy(wsl), *out["fragment"], *out["kept"], *out["primary"], *out["post"],
+                                 torch.tensor(point_num_avg), torch.tensor(radius_avg), len(sem), int(using_set_aggr), -1)
+    want = oracle.hierarchical_aggregation(sem, xyz, widx, wsl, b, using_set_aggr, point_num_avg, radius_avg, parts=True)
+    assert len(want["kept"][1]) > 2 and len(want["primary"][1]) > 3          # the case is not degenerate
+    groups = ("kept", "primary") + (("fragment", "post") if using_set_aggr else ())
+    for group in groups:
+        got = [t.numpy() for t in out[group]]
+        wi, wo = want[group][0], want[group][1]
+        assert np.array_equal(got[1], wo), group
+        if group == "post":     # allocated for every fragment + primary point, zero beyond the last offset (.cpp:166-169)
+            assert got[0].shape[0] == want["fragment"][0].shape[0] + want["primary"][0].shape[0]
+            assert not got[0][wo[-1]:].any()
+            got[0] = got[0][:wo[-1]]
+        assert np.array_equal(got[0].reshape(-1, 2), wi), group
+        if group != "post":     # centres: serial f32 sums in BFS order / size, class and scene of the seed (.cpp:84-88)
+            assert got[2].shape == (len(wo) - 1, 5) and np.array_equal(got[2], want[group][2]), group
+    if not using_set_aggr:      # the early return at .cpp:146-148 leaves these untouched
+        assert all(t.numel() == 0 for t in out["fragment"] + out["post"])
+    else:
+        assert want["post"][0].shape[0] > want["primary"][0].shape[0]        # something was absorbed
 
 
 def test_caller_allocated_outputs(OPS, oracle):

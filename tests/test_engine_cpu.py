@@ -100,6 +100,35 @@ def test_balanced_sampler_shards_and_matches_sizes():
     assert list(s2) == per_rank[0]                                        # and reproducible
 
 
+def test_balanced_sampler_has_no_systematic_straggler_and_flags_its_padding():
+    """the larger scenes of a step do not always go to the same rank (serpentine dealing, rotated per step), and the
+    wrap-around repeats that pad the shards are flagged so that validation can leave them out"""
+    from minsu3d_amd.parallel import BalancedDistributedBatchSampler
+    rng = np.random.default_rng(1)
+    sizes = rng.integers(40_000, 260_000, 403).tolist()
+    world = 4
+    for bs in (1, 2):
+        load = np.zeros(world)
+        wins = np.zeros(world)
+        samplers = [BalancedDistributedBatchSampler(sizes, bs, rank=r, world_size=world, seed=1) for r in range(world)]
+        per_rank = [list(s) for s in samplers]
+        for t in range(len(per_rank[0])):
+            step = [sum(sizes[i] for i in per_rank[r][t]) for r in range(world)]
+            load += step
+            wins[int(np.argmax(step))] += 1
+        assert load.max() / load.mean() < 1.01                    # epoch totals equal to 1 %
+        assert wins.max() / wins.sum() < 0.4                      # nobody is the slowest rank of (almost) every step
+    # validation: batch 1, no shuffle; 403 scans on 4 ranks -> 404 slots, exactly one flagged repeat, every scan once
+    val = [BalancedDistributedBatchSampler(sizes, 1, rank=r, world_size=world, shuffle=False) for r in range(world)]
+    kept = []
+    for s in val:
+        flags = s.padded_positions()
+        batches = list(s)
+        assert len(flags) == len(batches) == 101
+        kept += [b[0] for b, pad in zip(batches, flags) if not pad]
+    assert sorted(kept) == list(range(403))
+
+
 def _fit_worker(rank, world, port, root, out_dir, q):
     import sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

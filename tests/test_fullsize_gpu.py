@@ -172,6 +172,39 @@ def test_sg_bfs_cluster_one_full_scene_vs_oracle(be, oracle, noise):
     assert np.array_equal(o.cpu().numpy(), want[1]) and np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
 
 
+@pytest.mark.parametrize("seed", [0, 2])
+def test_pointgroup_original_coordinate_grouping_one_full_scene_vs_oracle(be, oracle, seed):
+    """model/pointgroup.py:57-65: the SECOND grouping of PointGroup -- ball query on the ORIGINAL coordinates (a few
+    neighbours per point, objects hundreds of BFS levels deep: the sparse-graph expansion of csrc/bfs_cluster.hip) and
+    pg_bfs_cluster on it -- one full ~150k-point scene, bit-exact against the oracle (bfs_cluster.cu:15-60,
+    bfs_cluster.cpp:28-54,86-101,131-166), cluster order and within-cluster FIFO order included"""
+    d = _inputs([seed])
+    widx, wsl = oracle.ballquery_batch_p(d["xyz"], d["batch_idxs"], d["batch_offsets"], RADIUS)
+    idx, sl = be.ballquery_batch_p(dev(d["xyz"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), RADIUS, 50)
+    assert np.array_equal(sl.cpu().numpy(), wsl) and np.array_equal(idx.cpu().numpy(), widx)
+    assert 4 * len(d["sem"]) < widx.size < 30 * len(d["sem"]) and wsl[:, 1].max() < 1000    # the sparse regime
+    for thr in (50, 1):
+        want = oracle.pg_bfs_cluster(d["sem"], widx, wsl, thr)
+        a, o = be.pg_bfs_cluster(dev(d["sem"]), idx, sl, thr)
+        assert len(want[1]) > 10
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    # and the whole merge of pointgroup.py:43-71 on this scene: original first, shifted renumbered behind it
+    wsi, wss = oracle.ballquery_batch_p(d["shifted"], d["batch_idxs"], d["batch_offsets"], RADIUS)
+    w_shift = oracle.pg_bfs_cluster(d["sem"], wsi, wss, 50)
+    w_orig = oracle.pg_bfs_cluster(d["sem"], widx, wsl, 50)
+    from minsu3d_amd.config import load_config
+    from minsu3d_amd.model import PointGroup
+    m = PointGroup(load_config([])).cuda()
+    obj = dev(d["object_idxs"])
+    p_shift, o_shift = m._group(dev(d["shifted"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), dev(d["sem"]), obj, 300)
+    p_orig, o_orig = m._group(dev(d["xyz"]), dev(d["batch_idxs"]), dev(d["batch_offsets"]), dev(d["sem"]), obj, 50)
+    for (gp, go), w in (((p_shift, o_shift), w_shift), ((p_orig, o_orig), w_orig)):
+        wi = w[0].reshape(-1, 2).astype(np.int64)
+        wi[:, 1] = d["object_idxs"][wi[:, 1]]                       # pointgroup.py:55,68: back to indices into all points
+        assert np.array_equal(go.cpu().numpy(), w[1]) and np.array_equal(gp.cpu().numpy(), wi)
+
+
 @pytest.mark.parametrize("cin,cout,level", [(32, 32, 0), (64, 64, 1), (96, 96, 2), (64, 32, 0)])
 def test_m32_adjoint_identities_at_bench_size(be, cin, cout, level):
     """the m = 32 widths of HAIS / SoftGroup on the benchmark's own tables: <conv_W(x), g> = <x, conv_W^T(g)> =

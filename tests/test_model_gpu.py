@@ -265,10 +265,53 @@ def test_one_launch_adam_matches_torch_adam():
             assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 20.0
         ob.load_state_dict(oa.state_dict())          # torch's Adam continues from our state, and the other way round
         oa.load_state_dict(ob.state_dict())
-        for a in pa:
+        for a, b in zip(pa, pb):
             a.grad = torch.ones_like(a)
-        oa.step()
-        assert float(oa.state[pa[0]]["step"]) == 21.0
+            b.grad = torch.ones_like(b)
+        oa.step(); ob.step()
+        steps = [ob.state[b]["step"] for b in pb]
+        assert all(float(t) == 21.0 for t in steps)                  # one increment per parameter, not one per alias
+        assert len({id(t) for t in steps}) == len(steps)
+        assert all(float(oa.state_dict()["state"][i]["step"]) == 21.0 for i in range(len(pa)))
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_starts_each_parameter_at_its_own_first_gradient():
+    """torch.optim.Adam keeps one step counter per parameter and creates it with the parameter's first gradient: the
+    ScoreNet / refinement branches get gradients only after `prepare_epochs` (pointgroup.py:25, hais.py:30,
+    softgroup.py:34) and must then be bias-corrected as step 1, 2, ... while the backbone is thousands of steps in"""
+    from minsu3d_amd.optim import Adam
+    g = torch.Generator().manual_seed(9)
+    shapes = [(27, 16, 16), (16,), (5000,), (33,), (16, 1)]
+    late = (2, 4)                                                    # these see their first gradient at step 10
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = Adam(pa, lr=2e-3), torch.optim.Adam(pb, lr=2e-3)
+    for step in range(25):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i in late and (step < 10 or step == 17):              # ... and skip one step later on
+                a.grad = b.grad = None
+                continue
+            a.grad = torch.randn(a.shape, generator=g).cuda()
+            b.grad = a.grad.clone()
+        oa.step(); ob.step()
+        if step in (9, 10, 12, 24):
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (step, i, float((a - b).abs().max()))
+    sd = oa.state_dict()["state"]
+    assert [float(sd[i]["step"]) for i in range(5)] == [25.0, 25.0, 14.0, 25.0, 14.0]
+    assert [float(ob.state[b]["step"]) for b in pb] == [25.0, 25.0, 14.0, 25.0, 14.0]
+    # resumed from a state whose counters differ per parameter: continues per parameter
+    oc = Adam(pa, lr=2e-3)
+    oc.load_state_dict(oa.state_dict())
+    for a, b in zip(pa, pb):
+        a.grad = torch.ones_like(a); b.grad = torch.ones_like(b)
+    oc.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7)
+    assert [float(oc.state_dict()["state"][i]["step"]) for i in range(5)] == [26.0, 26.0, 15.0, 26.0, 15.0]
 
 
 @pytest.mark.gpu

@@ -57,6 +57,31 @@ def test_oracle_vs_reference_live(oracle):
         assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
 
 
+@pytest.mark.parametrize("set_aggr", [False, True])
+def test_hais_raw_lists_are_consistent_with_the_merged_result(oracle, golden_dir, set_aggr):
+    """parts=True (the lists hierarchical_aggregation.cpp:133-175 leaves in the caller's tensors): merged the way the
+    wrapper merges them they are the oracle's merged result -- which the golden case pins for point aggregation --
+    and every primary's post list starts with the primary itself"""
+    g = np.load(os.path.join(golden_dir, "bfs_case1.npz"))
+    args = (g["sem"], g["xyz"], g["ball_idx"], g["start_len"], g["batch_idxs"], set_aggr, g["point_num_avg"], g["radius_avg"])
+    parts = oracle.hierarchical_aggregation(*args, parts=True)
+    merged = oracle.hierarchical_aggregation(*args)
+    ki, ko = parts["kept"][:2]
+    pi, po = parts["post" if set_aggr else "primary"][:2]
+    pi = pi.copy(); pi[:, 0] += len(ko) - 1
+    assert np.array_equal(np.concatenate([ki, pi]), merged[0].reshape(-1, 2))
+    assert np.array_equal(np.concatenate([ko, po[1:] + ko[-1]]), merged[1])
+    if not set_aggr:
+        assert np.array_equal(merged[0], g["hais_idxs"]) and parts["post"][0].shape[0] == 0
+    else:
+        raw_i, raw_o = parts["primary"][:2]
+        for c in range(len(raw_o) - 1):
+            m = raw_o[c + 1] - raw_o[c]
+            assert np.array_equal(parts["post"][0][po[c]:po[c] + m, 1], raw_i[raw_o[c]:raw_o[c + 1], 1])
+    fi, fo, fc = parts["fragment"]
+    assert set(map(tuple, ki[:, 1:])) <= set(map(tuple, fi[:, 1:])) and fc.shape == (len(fo) - 1, 5)
+
+
 def test_ballquery_brute_force_numpy(oracle):
     """independent check of the oracle's ball query against a numpy f64-free restatement"""
     rng = np.random.default_rng(3)

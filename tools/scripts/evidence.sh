@@ -1,5 +1,5 @@
 # usage: bash tools/scripts/evidence.sh <tag> <commit>   -> gpurun_out/<tag>_*  (bench JSON lines, kernel stats, PMC traffic, timelines)
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1; export TMPDIR=/tmp
 TAG=$1; C=$2
 for M in pointgroup hais softgroup; do
   bash tools/scripts/pmc_traffic.sh $M $C > /dev/null 2>&1

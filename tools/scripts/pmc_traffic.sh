@@ -1,5 +1,5 @@
 # usage: bash tools/scripts/pmc_traffic.sh <model> <commit>  -> gpurun_out/r02_traffic_<model>.json
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1; export TMPDIR=/tmp
 M=$1; C=$2
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$ctr
