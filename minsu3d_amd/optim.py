@@ -39,18 +39,20 @@ class Adam(torch.optim.Adam):
     def _plan(self, gi, params):
         key = tuple(id(p) for p in params)
         plan = self._plans.get(gi)
-        if plan is not None and plan["key"] == key:
+        if plan is not None and plan["key"] == key and self.state[params[0]].get("step") is plan["first_view"]:
             return plan
-        # the set of parameters with gradients changed (a branch switched on after `prepare_epochs`, a resumed state):
-        # hand the running counters back to the state dictionary, then read every parameter's OWN counter
-        self._flush()
+        # (re)built when the set of parameters with gradients changes -- a branch switched on after `prepare_epochs` --
+        # or after load_state_dict; every parameter's OWN counter is read from the state
         lib = get_backend().lib
         chunk = lib.ms3d_adam_chunk_elems()
         dev = params[0].device
         rows = []
         for t, p in enumerate(params):
             rows += [(t, c) for c in range(-(-p.numel() // chunk))]
-        steps = np.zeros(len(params), np.float64)
+        # The per-parameter step counters are 0-dim views into ONE host tensor: `steps += 1` is a single operation per
+        # step (250 scalar tensor increments would cost the interpreter ~1 ms) while state[p]['step'] stays what
+        # torch.optim.Adam keeps there -- a float32 scalar tensor per parameter, each with its own value.
+        steps = torch.zeros(len(params), dtype=torch.float32)
         for t, p in enumerate(params):
             st = self.state[p]
             if len(st) == 0:                     # torch.optim.Adam's lazy state: a parameter's counter starts with its
@@ -58,8 +60,10 @@ class Adam(torch.optim.Adam):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             steps[t] = float(st["step"])
+            st["step"] = steps[t]
         host = [torch.empty((5, len(params)), dtype=torch.int64).pin_memory() for _ in range(_RING)]
-        plan = dict(key=key, lib=lib, n=len(params), n_chunks=len(rows), params=list(params), steps=steps,
+        plan = dict(key=key, lib=lib, n=len(params), n_chunks=len(rows), steps=steps, steps_np=steps.numpy(),
+                    first_view=self.state[params[0]]["step"],
                     chunks=torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).to(dev),
                     sizes=torch.tensor([p.numel() for p in params], dtype=torch.int64).to(dev),
                     host=host, host_np=[h.numpy() for h in host],
@@ -67,18 +71,13 @@ class Adam(torch.optim.Adam):
         self._plans[gi] = plan
         return plan
 
-    def _flush(self):
-        """the per-parameter step counters live in a host array between steps (250 scalar tensor increments per step
-        would cost the interpreter ~1 ms); this writes them back as torch.optim.Adam keeps them: ONE float32 scalar
-        tensor per parameter, no two parameters sharing a tensor"""
-        for plan in self._plans.values():
-            for p, t in zip(plan["params"], plan["steps"]):
-                self.state[p]["step"] = torch.tensor(float(t), dtype=torch.float32)
-        self._plans = {}
-
     def state_dict(self):
-        self._flush()
-        return super().state_dict()
+        """torch.optim.Adam's layout; the step counters are handed out as independent scalar tensors (torch's
+        load_state_dict keeps the very tensor objects it is given)"""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (v.clone() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
 
     def load_state_dict(self, state_dict):
         self._plans = {}
@@ -93,7 +92,6 @@ class Adam(torch.optim.Adam):
                 loss = closure()
         groups = [(gi, g, [p for p in g["params"] if p.grad is not None]) for gi, g in enumerate(self.param_groups)]
         if not all(self._eligible(g, ps) for _, g, ps in groups if ps):
-            self._flush()
             super().step()
             return loss
         for gi, group, params in groups:
@@ -102,7 +100,7 @@ class Adam(torch.optim.Adam):
             beta1, beta2 = group["betas"]
             plan = self._plan(gi, params)
             plan["steps"] += 1.0
-            t = plan["steps"]
+            t = plan["steps_np"].astype(np.float64)
             turn = plan["turn"]
             plan["turn"] = (turn + 1) % _RING
             hn = plan["host_np"][turn]
