@@ -17,8 +17,10 @@ nM*(Cin+Cout)*4 + nM*8 + K*Cin*Cout*4 with each table's real pair count nM, divi
 and `top_kernels` lists the five largest kernel groups by time (convolutions by variant and shape, and the grouping
 operators with their SURVEY 8d byte formulas).  `traffic` (HBM bytes of the same convolution kernels per step, from
 PMC counters) needs separate rocprofv3 --pmc passes, which this script cannot run on itself: it is read from
-profiles/r02_traffic_<model>.json (made by tools/scripts/pmc_traffic.sh from FETCH_SIZE / WRITE_SIZE passes of this
-script at the commit named there; corrections as MI355X_MICROARCH.md prescribes) and is null when that file is absent.
+profiles/r03_traffic_<model>.json (made by tools/scripts/pmc_traffic.sh from FETCH_SIZE / WRITE_SIZE passes of this
+script; corrections as MI355X_MICROARCH.md prescribes) and is null when that file is absent or carries the digest of
+other kernel sources than the ones running (`kernel_source_digest`).  `step_ms` = median / min / max / mean of the
+per-step durations between HIP events at the step boundaries; `ms_per_step` = wall time of the timed region / steps.
 
 `cpu_baseline` times the same training step on the host cores with every operator served by the CPU oracle (a PORT
 of the reference algorithms -- the reference's own CPU path needs MinkowskiEngine, which is not available), on a
@@ -173,6 +175,17 @@ def _conv_variant(kind, K, cin, cout, rows, lib):
     return "pair-list" if listed and max(cin, cout) <= 32 else "table-walk"
 
 
+def kernel_source_digest():
+    """sha256[:16] over the convolution kernels' sources: a committed PMC traffic file carries the digest of the code it
+    was measured on, and `roofline.traffic` is reported only when that is the code running now"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("spconv.hip", "coords.hip", "common.h"):
+        with open(os.path.join(ROOT, "minsu3d_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     """groups: KernelTimer.summary() over `n_sampled` steps -> (roofline dict, top_kernels list)"""
     if not groups or n_sampled == 0:
@@ -193,12 +206,16 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     # HBM bytes of the same kernels from the PMC passes committed with this code (separate rocprofv3 --pmc FETCH_SIZE /
     # --pmc WRITE_SIZE runs of this script, tools/scripts/pmc_traffic.sh); null when the file is missing or is for
     # another model
-    tfile = os.path.join(ROOT, "profiles", f"r02_traffic_{model_name}.json")
+    tfile = os.path.join(ROOT, "profiles", f"r03_traffic_{model_name}.json")
     if os.path.exists(tfile):
         with open(tfile) as fh:
             t = json.load(fh)
-        roof["traffic"] = t.get("spconv_hbm_bytes_per_step")
-        roof["traffic_source"] = f"profiles/{os.path.basename(tfile)} ({t.get('commit', '?')}): {t.get('method', '')}"
+        if t.get("kernel_source_digest") == kernel_source_digest():
+            roof["traffic"] = t.get("spconv_hbm_bytes_per_step")
+            roof["traffic_source"] = f"profiles/{os.path.basename(tfile)} ({t.get('commit', '?')}): {t.get('method', '')}"
+        else:   # counters of other code are not this code's traffic
+            roof["traffic_source"] = (f"profiles/{os.path.basename(tfile)} was measured on other kernel sources "
+                                      f"(digest {t.get('kernel_source_digest')} != {kernel_source_digest()}): not reported")
     rows = []
     for k, v in groups.items():
         if k[0].startswith("spconv_"):
@@ -226,7 +243,7 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     return roof, top
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -242,47 +259,67 @@ def main():
     ap.add_argument("--cpu-config1", action="store_true", help="cpu_baseline on BASELINE config 1 (4 x ~20k-point scenes)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="print every timed kernel group to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--override", action="append", default=[], help="Hydra-style key=value on top of the model's config")
+    ap.add_argument("--scene", default=None, help="JSON keyword arguments of synthetic.make_scene (smaller scenes)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu = DRY RUN of the launch / sharding / barrier / max-over-ranks / reporting path on host "
+                         "tensors over gloo (tests/bench_dryrun.py installs the operator backend); never a measurement")
+    args = ap.parse_args(argv)
+    dry = args.device == "cpu"
 
     rank, local, world = init_distributed()
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-    cfg = load_config([f"model={args.model}", "data=scannetv2"])
+    device = torch.device("cpu") if dry else torch.device("cuda", local)
+    if not dry:
+        torch.cuda.set_device(device)
+    cfg = load_config([f"model={args.model}", "data=scannetv2"] + list(args.override))
     be = ms_backend.get_backend()          # raises if libminsu3d_hip.so is missing: no fallback
 
     model = build(cfg, device)
     ddp = wrap_ddp(model, device, find_unused_parameters=False)   # grouping branch on: every parameter gets a gradient
     opt = model.configure_optimizers()
     scene_kwargs = None if args.density == 1700.0 else {"density": args.density}
+    if args.scene:
+        scene_kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(args.scene).items()}
     batches = [make_batch(shard_scene_seeds(s, args.batch, rank, world), device, scene_kwargs) for s in range(args.pool)]
     n_pts = float(np.mean([b["point_xyz"].shape[0] for b in batches])) / args.batch
     n_vox = float(np.mean([b["voxel_xyz"].shape[0] for b in batches])) / args.batch
 
     timer = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline and rank == 0 and not dry:
         timer = ms_backend.KernelTimer(be.lib)
         timer.reserve(700 * (args.steps // SAMPLE_EVERY + 1))
         be.kernel_timer = timer
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
     for i in range(args.warmup):
         train_step(model, ddp, opt, batches[i % args.pool], batches[(i + 1) % args.pool])
     sync_all()
     n_sampled = 0
+    # per-step durations on the GPU's clock: one event per step boundary on the main stream (recording costs ~2 us of
+    # host time and no synchronisation); `ms_per_step` stays wall time / steps
+    class _HostMark:        # dry run: host clock
+        def record(self): self.t = time.perf_counter()
+        def elapsed_time(self, other): return 1000.0 * (other.t - self.t)
+    marks = [_HostMark() if dry else torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         if timer is not None:
             timer.sampling = i % SAMPLE_EVERY == SAMPLE_EVERY // 2
             n_sampled += int(timer.sampling)
         loss = train_step(model, ddp, opt, batches[i % args.pool], batches[(i + 1) % args.pool])
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -294,7 +331,11 @@ def main():
         line = {
             "metric": f"scenes/sec (fwd+bwd) {cfg.model.network.module} on ~150k-pt 2cm voxels",
             "value": round(scenes / dt, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
+            "step_ms": {"median": round(float(np.median(step_ms)), 3), "min": round(float(step_ms.min()), 3),
+                        "max": round(float(step_ms.max()), 3), "mean": round(float(step_ms.mean()), 3),
+                        "clock": "HIP events at the step boundaries on the main stream (rank 0)"},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.model.network.module} m={cfg.model.network.m}, synthetic ScanNet-shaped scenes "
                                    f"(~{n_pts / 1000:.0f}k points, ~{n_vox / 1000:.0f}k voxels @2cm each), "
@@ -315,7 +356,9 @@ def main():
                 for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
                     print(f"{v['ms'] / max(n_sampled, 1):8.3f} ms/step {v['launches'] / max(n_sampled, 1):6.1f} launches "
                           f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            line["dry_run"] = "host tensors over gloo: exercises the launch path only, the numbers mean nothing"
+        if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(cfg, config1=args.cpu_config1)
         print(json.dumps(line), flush=True)
     if world > 1:

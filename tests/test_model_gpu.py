@@ -263,8 +263,10 @@ def test_one_launch_adam_matches_torch_adam():
             assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
             assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=2e-5, atol=1e-12)   # 20 steps of f32 rounding (torch: separate mul_ and addcmul_)
             assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 20.0
-        ob.load_state_dict(oa.state_dict())          # torch's Adam continues from our state, and the other way round
-        oa.load_state_dict(ob.state_dict())
+        # torch's Adam continues from our state, and the other way round (deep copies, as a checkpoint file gives them:
+        # torch's load_state_dict keeps the tensor objects it is handed)
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        oa.load_state_dict(copy.deepcopy(ob.state_dict()))
         for a, b in zip(pa, pb):
             a.grad = torch.ones_like(a)
             b.grad = torch.ones_like(b)
@@ -305,7 +307,7 @@ def test_one_launch_adam_starts_each_parameter_at_its_own_first_gradient():
     assert [float(ob.state[b]["step"]) for b in pb] == [25.0, 25.0, 14.0, 25.0, 14.0]
     # resumed from a state whose counters differ per parameter: continues per parameter
     oc = Adam(pa, lr=2e-3)
-    oc.load_state_dict(oa.state_dict())
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
     for a, b in zip(pa, pb):
         a.grad = torch.ones_like(a); b.grad = torch.ones_like(b)
     oc.step(); ob.step()

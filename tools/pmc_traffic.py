@@ -3,7 +3,7 @@ the TCC has too few slots for both).  Corrections as /opt/skills/guides/MI355X_M
 both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide reads at 64 B -> fetch x 2; WRITE_SIZE
 is taken as reported.
 usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up>
-                                   <model> <commit> > profiles/r02_traffic_<model>.json"""
+                                   <model> <commit> > profiles/r03_traffic_<model>.json"""
 import csv, sys, json, re, collections
 
 
@@ -26,8 +26,11 @@ for k in sorted(set(fetch) | set(write)):
                  "hbm_bytes_per_step": int((2.0 * f[1] + w[1]) / steps)})
 rows.sort(key=lambda r: -r["hbm_bytes_per_step"])
 conv = [r for r in rows if r["kernel"].startswith("spconv_")]
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 print(json.dumps({
-    "model": model, "commit": commit,
+    "model": model, "commit": commit, "kernel_source_digest": bench.kernel_source_digest(),
     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py "
               f"--model {model} --steps 2 --warmup 1 --no-cpu-baseline --no-roofline; bytes = (2 x FETCH_SIZE + WRITE_SIZE) "
               "x 1024 (KB units; gfx950 FETCH_SIZE counts 128-B requests of wide reads as 64 B), summed per kernel, "
