@@ -353,6 +353,7 @@ def main(argv=None):
             if roof:
                 line["roofline"], line["top_kernels"] = roof, top
             if args.all_kernels:
+                print("step_ms: " + " ".join(f"{t:.2f}" for t in step_ms), file=sys.stderr)
                 for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
                     print(f"{v['ms'] / max(n_sampled, 1):8.3f} ms/step {v['launches'] / max(n_sampled, 1):6.1f} launches "
                           f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}", file=sys.stderr)

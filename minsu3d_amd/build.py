@@ -10,6 +10,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libminsu3d_hip.so")
 OBJ_DIR = os.path.join(HERE, "..", "build", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MS3D_EXTRA_HIPCC_FLAGS", "").split()     # experiment builds (knock-out variants)
 
 
 def _sources():
