@@ -262,7 +262,9 @@ def test_training_step_at_bench_size(name):
 
 
 # --------------------------------------------------------------------------- the 1e-4 activation bar, end to end
-def _ref_conv(x, W, nbr):
+def _ref_conv(x, W, nbr, cast=None):
+    if cast is not None:
+        W = cast(W)
     xp = torch.cat([x, x.new_zeros(1, x.size(1))], 0)
     out = x.new_zeros(nbr.size(1), W.size(2))
     for k in range(nbr.size(0)):
@@ -272,33 +274,40 @@ def _ref_conv(x, W, nbr):
     return out
 
 
-def _ref_bn_relu(x, mbn):
+_REF_RELU = True        # the gradient test also runs the restatement (and the engine) without the ReLUs
+
+
+def _ref_bn_relu(x, mbn, cast=None):
     bn = mbn.bn
-    return torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight.double(), bn.bias.double(), True, 0.1, bn.eps))
+    c = cast or (lambda t: t.double())
+    z = torch.nn.functional.batch_norm(x, None, None, c(bn.weight), c(bn.bias), True, 0.1, bn.eps)
+    return torch.relu(z) if _REF_RELU else z
 
 
-def _ref_block(h, blk, nbr):
-    skip = h if blk.downsample is None else h @ blk.downsample[0].kernel.double()
+def _ref_block(h, blk, nbr, cast=None):
+    c = cast or (lambda t: t.double())
+    skip = h if blk.downsample is None else h @ c(blk.downsample[0].kernel)
     cb = blk.conv_branch
-    a = _ref_conv(_ref_bn_relu(h, cb[0]), cb[2].kernel.double(), nbr)
-    a = _ref_conv(_ref_bn_relu(a, cb[3]), cb[5].kernel.double(), nbr)
+    a = _ref_conv(_ref_bn_relu(h, cb[0], cast), c(cb[2].kernel), nbr)
+    a = _ref_conv(_ref_bn_relu(a, cb[3], cast), c(cb[5].kernel), nbr)
     return a + skip
 
 
-def _ref_ublock(h, ub, cm, ts, acts):
+def _ref_ublock(h, ub, cm, ts, acts, cast=None):
+    c = cast or (lambda t: t.double())
     nbr = cm.k3(ts)
     for blk in ub.blocks:
-        h = _ref_block(h, blk, nbr)
+        h = _ref_block(h, blk, nbr, cast)
     acts.append(h)
     if len(ub.nPlanes) == 1:
         return h
     down, up = cm.k2(ts)
-    d = _ref_conv(_ref_bn_relu(h, ub.conv[0]), ub.conv[2].kernel.double(), down)
-    d = _ref_ublock(d, ub.u, cm, 2 * ts, acts)
-    u = _ref_conv(_ref_bn_relu(d, ub.deconv[0]), ub.deconv[2].kernel.double(), up)
+    d = _ref_conv(_ref_bn_relu(h, ub.conv[0], cast), c(ub.conv[2].kernel), down)
+    d = _ref_ublock(d, ub.u, cm, 2 * ts, acts, cast)
+    u = _ref_conv(_ref_bn_relu(d, ub.deconv[0], cast), c(ub.deconv[2].kernel), up)
     h = torch.cat([h, u], 1)
     for blk in ub.blocks_tail:
-        h = _ref_block(h, blk, nbr)
+        h = _ref_block(h, blk, nbr, cast)
     acts.append(h)
     return h
 
@@ -352,6 +361,80 @@ def test_backbone_activations_within_1e4_of_fp64_on_a_full_scene():
     err = ((y.double() - want).abs().max() / want.abs().max()).item()
     assert err <= 1e-4, err
     print(f"backbone activations vs fp64: worst level {worst:.2e}, output {err:.2e}")
+
+
+@pytest.mark.parametrize("with_relu", [False, True])
+def test_unet_gradients_vs_fp64_on_a_full_scene(with_relu):
+    """Gradients end to end: a two-level U-Net (input convolution, 2 + 2 + 2 residual blocks, strided and transposed
+    convolution, skip concatenation, 1x1 projection, 14 batch norms -- every backward kernel of the engine: backward-data
+    with the fused BatchNorm backward, backward-weight on offset lists and tables, the BatchNorm backward chain, the
+    concatenation split) on one full ~106k-voxel benchmark scene, loss = <output, fixed random tensor>; every
+    parameter's gradient against float64 autograd through the gather-matmul restatement above.
+
+    with_relu=False (every MinkowskiReLU replaced by the identity: the network is smooth): ALL tensors within 1e-4 of
+    their largest entry.  with_relu=True: the network is only piecewise smooth -- an activation the engine's float32
+    forward puts 1e-6 on the other side of zero than float64 does flips its ReLU mask, and each flip moves a gradient
+    sum by a whole term (~10^2 such elements among the 10^7 activations of this net); the bar there is 2e-2 per tensor
+    with the forward activations themselves within 1e-4."""
+    global _REF_RELU
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from minsu3d_amd.data import synthetic
+    from minsu3d_amd.model.module import Backbone
+    import minsu3d_amd.MinkowskiEngine as ME
+    backend.set_backend(HipBackend())
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(11)
+    net = Backbone(input_channel=6, output_channel=16, block_channels=[1, 2], block_reps=2, sem_classes=20).to(dev).train()
+    unet = net.unet
+    if not with_relu:
+        for parent in list(unet.modules()):
+            for name, child in list(parent.named_children()):
+                if isinstance(child, ME.MinkowskiReLU):
+                    setattr(parent, name, torch.nn.Identity())
+    with torch.no_grad():                                   # BatchNorm scales / shifts away from their 1 / 0 start
+        for n_, p_ in unet.named_parameters():
+            if n_.endswith("bn.weight"):
+                p_.uniform_(0.6, 1.4)
+            elif n_.endswith("bn.bias"):
+                p_.uniform_(-0.3, 0.3)
+    b = synthetic.to_torch(synthetic.collate([synthetic.make_scene(6)]), dev)
+    x = ME.SparseTensor(features=b["voxel_features"], coordinates=b["voxel_xyz"])
+    cm = x.coordinate_manager
+    cm.prepare(2)
+    R = torch.randn(b["voxel_xyz"].size(0), 16, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    ME.prepare_conv_weights(net)
+    try:
+        y = unet(x)
+    finally:
+        ME.release_conv_weights()
+    # the loss is taken over the engine's row order on both sides (the restatement works on the engine's kernel maps)
+    (y._raw() * R).sum().backward()
+    got = {n_: p_.grad.detach().clone() for n_, p_ in unet.named_parameters()}
+    assert len(got) >= 40 and all(torch.isfinite(g).all().item() for g in got.values())
+    unet.zero_grad(set_to_none=True)
+    _REF_RELU = with_relu
+    try:
+        acts = []
+        h = _ref_conv(x._raw().detach().double(), unet[0].kernel.double(), cm.k3(1))
+        h = _ref_ublock(h, unet[1], cm, 1, acts)
+        want_y = _ref_bn_relu(h, unet[2])
+    finally:
+        _REF_RELU = True
+    assert ((y._raw().detach().double() - want_y).abs().max() / want_y.abs().max()).item() <= 1e-4
+    (want_y * R.double()).sum().backward()
+    errs = []
+    for n_, p_ in unet.named_parameters():
+        w = p_.grad.double()
+        assert w.abs().max() > 0, n_
+        errs.append((((got[n_].double() - w).abs().max() / w.abs().max()).item(), n_))
+    errs.sort(reverse=True)
+    med = errs[len(errs) // 2][0]
+    print(f"U-Net gradients vs fp64 autograd (ReLU {'on' if with_relu else 'off'}): worst {errs[0][0]:.2e} ({errs[0][1]}), "
+          f"median {med:.2e}, {sum(e <= 1e-4 for e, _ in errs)} of {len(errs)} tensors within 1e-4")
+    bar = 2e-2 if with_relu else 1e-4
+    for e, n_ in errs:
+        assert e <= bar, (n_, e)
 
 
 def test_scatter_add_rows_vs_index_add(be):

@@ -49,7 +49,14 @@ def test_pointgroup_step_hip_vs_oracle():
     assert rel(out_h["proposal_scores"][0], out_r["proposal_scores"][0]) < 5e-3
     for k in loss_r:
         assert abs(float(loss_h[k].detach()) - float(loss_r[k].detach())) < 2e-3 * max(1.0, abs(float(loss_r[k].detach()))), k
+    # Gradients: both sides are float32 evaluations of a piecewise-smooth 60-layer network on tiny scenes (proposal grids
+    # of a few hundred voxels behind BatchNorm), so a handful of ReLU masks differ between the two roundings and each
+    # flip moves a gradient sum by a whole term.  The smooth comparison -- every backward kernel against float64 autograd
+    # at bench size, all tensors within 1e-4 (measured 3e-6) -- is
+    # tests/test_fullsize_gpu.py::test_unet_gradients_vs_fp64_on_a_full_scene; here the bar is that no tensor is off by
+    # more than a few flipped terms and that the typical tensor agrees to float32 accumulation noise.
     gr = dict(ref_model.named_parameters())
+    errs = []
     for n, p in hip_model.named_parameters():
         if gr[n].grad is None:
             assert p.grad is None
@@ -57,7 +64,11 @@ def test_pointgroup_step_hip_vs_oracle():
         if gr[n].grad.abs().max() < 1e-6:      # mathematically zero (e.g. a Linear bias in front of BatchNorm1d)
             assert p.grad.abs().max() < 1e-5, n
             continue
-        assert rel(p.grad, gr[n].grad) < 3e-2, n
+        errs.append((rel(p.grad, gr[n].grad), n))
+    errs.sort(reverse=True)
+    print(f"gradients HIP vs oracle backend: worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    assert errs[0][0] < 3e-2, errs[0]
+    assert errs[len(errs) // 2][0] < 2e-3, errs[len(errs) // 2]
 
 
 def test_step_is_reproducible_on_device():
