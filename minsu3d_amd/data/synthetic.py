@@ -12,8 +12,10 @@ def _sample_rect(rng, origin, eu, ev, density):
     return origin + uv[:, :1] * eu + uv[:, 1:] * ev
 
 
-def make_scene(seed, room=(5.0, 4.0), n_boxes=12, density=1700.0, wall_h=1.6):
-    """-> dict(xyz f32[N,3], rgb f32[N,3] in [-1,1], sem_labels i16[N], instance_ids i16[N])"""
+def make_scene(seed, room=(5.0, 4.0), n_boxes=12, density=1700.0, wall_h=1.6, n_box_classes=18, class_colours=False):
+    """-> dict(xyz f32[N,3], rgb f32[N,3] in [-1,1], sem_labels i16[N], instance_ids i16[N]).
+    class_colours: the colour of a point tells its class (palette + N(0, 0.15)) -- the LEARNABLE variant used by the
+    convergence test; the benchmark's scenes keep uniform random colours (labels there are not predictable)."""
     rng = np.random.default_rng(seed)
     L, Wd = room
     pts, sem, inst = [], [], []
@@ -34,13 +36,16 @@ def make_scene(seed, room=(5.0, 4.0), n_boxes=12, density=1700.0, wall_h=1.6):
         faces = [(np.array([lo[0], lo[1], hi[2]]), sx, sy),                      # top (bottom face omitted)
                  (lo, sx, sz), (np.array([lo[0], hi[1], 0.]), sx, sz), (lo, sy, sz), (np.array([hi[0], lo[1], 0.]), sy, sz)]
         p = np.concatenate([_sample_rect(rng, o, eu, ev, density) for o, eu, ev in faces], 0)
-        add(p, 2 + (b % 18), b)
+        add(p, 2 + (b % n_box_classes), b)
     xyz = np.concatenate(pts, 0) + rng.normal(0, 0.003, (sum(len(p) for p in pts), 3))
     perm = rng.permutation(len(xyz))           # scan order is not face order
     xyz = xyz[perm].astype(np.float32)
     sem = np.concatenate(sem)[perm]
     inst = np.concatenate(inst)[perm]
     rgb = rng.uniform(-1, 1, (len(xyz), 3)).astype(np.float32)
+    if class_colours:
+        palette = np.random.default_rng(12345).uniform(-0.8, 0.8, (20, 3))
+        rgb = np.clip(palette[sem] + rng.normal(0, 0.15, (len(xyz), 3)), -1, 1).astype(np.float32)
     xyz -= xyz.mean(0)                          # general_dataset.py:24
     return dict(xyz=xyz, rgb=rgb, sem_labels=sem, instance_ids=inst)
 
