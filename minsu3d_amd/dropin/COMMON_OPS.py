@@ -61,7 +61,58 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, meanAct
         int(batch_offsets.numel() - 1), 0, _lib.ptr(idx), _lib.ptr(start_len), C.byref(n_active), C.byref(capped),
         _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_ballquery_batch_p")
     start_len._ms3d_capped = int(capped.value)
+    _remember_graph(idx, start_len, int(n_active.value), int(capped.value))
     return int(n_active.value)
+
+
+# ---- the reference's host round trip without the PCIe traffic -------------------------------------------------
+# model/pointgroup.py:43-55 (hais.py:45-56, softgroup.py:54-63) moves the ball-query result to the host
+# (`idx.cpu()`, `start_len.cpu()`: up to n * 300 * 4 B ~ 150 MB per call), clusters there and moves the clusters
+# back.  Run unchanged against this module that is two PCIe trips of the whole neighbour list per grouping for a BFS
+# that runs on the GPU anyway.  The last two ball-query results are therefore remembered ON THE DEVICE together with a
+# fingerprint (sizes + _FP_N sampled entries of both tensors, fetched with the hit count the call already reads back);
+# a clustering call that is handed HOST tensors with the same fingerprint takes the device copies instead of
+# uploading them.  A host tensor that was edited between the two calls at one of the other positions would be
+# mistaken for the original: MS3D_DROPIN_REUSE=0 switches the shortcut off.
+_FP_N = 4096
+_GRAPHS = []          # newest first: dict(n_active, n, fp_idx, fp_sl, pos_idx, pos_sl, idx, start_len, capped)
+_REUSE_HITS = [0, 0]  # (device copies taken, host tensors uploaded) -- read by tests / tools
+
+
+def _positions(numel, dev):
+    if numel <= 0:
+        return torch.zeros(0, dtype=torch.long, device=dev)
+    g = torch.Generator().manual_seed(numel)
+    return torch.randint(0, numel, (min(_FP_N, numel),), generator=g).to(dev)
+
+
+def _remember_graph(idx, start_len, n_active, capped):
+    import os
+    if os.environ.get("MS3D_DROPIN_REUSE", "1") == "0" or n_active > idx.numel():
+        return
+    pos_i, pos_s = _positions(n_active, idx.device), _positions(start_len.numel(), idx.device)
+    fp = torch.cat((idx[pos_i], start_len.view(-1)[pos_s])).cpu()          # one small device->host read
+    _GRAPHS.insert(0, dict(n_active=n_active, n=start_len.size(0), pos_idx=pos_i.cpu(), pos_sl=pos_s.cpu(),
+                           fp_idx=fp[:pos_i.numel()], fp_sl=fp[pos_i.numel():], idx=idx, start_len=start_len,
+                           capped=capped, v_idx=idx._version, v_sl=start_len._version))
+    del _GRAPHS[2:]
+
+
+def _device_graph(ball_query_idxs, start_len):
+    """the device copies of a ball-query result handed in as HOST tensors, or the arguments themselves"""
+    if ball_query_idxs.is_cuda or start_len.is_cuda:
+        return ball_query_idxs, start_len
+    for g in _GRAPHS:
+        if (g["n_active"] == ball_query_idxs.numel() and g["n"] == start_len.size(0)
+                and g["idx"]._version == g["v_idx"] and g["start_len"]._version == g["v_sl"]   # not written since
+                and torch.equal(ball_query_idxs.view(-1)[g["pos_idx"]], g["fp_idx"])
+                and torch.equal(start_len.reshape(-1)[g["pos_sl"]], g["fp_sl"])):
+            _REUSE_HITS[0] += 1
+            sl = g["start_len"]
+            sl._ms3d_capped = g["capped"]
+            return g["idx"][:g["n_active"]], sl
+    _REUSE_HITS[1] += 1
+    return ball_query_idxs, start_len
 
 
 def _seg(name, inp, offsets, out, nProposal, C_):
@@ -140,6 +191,7 @@ def get_mask_label(proposals_idx, proposals_offset, instance_labels, instance_cl
 def pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, cluster_idxs, cluster_offsets, N, threshold):
     """bfs_cluster.cpp:140-166: cluster_idxs -> i32[sumNPoint,2], cluster_offsets -> i32[nCluster+1] (resized)"""
     assert int(N) == start_len.size(0)
+    ball_query_idxs, start_len = _device_graph(ball_query_idxs, start_len)
     idxs, offs = _be().pg_bfs_cluster(semantic_label, ball_query_idxs, start_len, int(threshold))
     _assign(cluster_idxs, idxs)
     _assign(cluster_offsets, offs)
@@ -149,6 +201,7 @@ def sg_bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, cluster_idxs
                    class_id):
     """bfs_cluster.cpp:168-187; class_numpoint_mean is a float32 CPU tensor (functions/softgroup_ops.py:23)"""
     assert int(N) == start_len.size(0)
+    ball_query_idxs, start_len = _device_graph(ball_query_idxs, start_len)
     idxs, offs = _be().sg_bfs_cluster([float(v) for v in class_numpoint_mean.tolist()], ball_query_idxs, start_len,
                                       float(threshold), int(class_id))
     _assign(cluster_idxs, idxs)
@@ -167,6 +220,7 @@ def hierarchical_aggregation(semantic_label, coord_shift, batch_idxs, ball_query
     in ascending fragment index (the reference's order depends on atomics)."""
     assert int(N) == start_len.size(0)
     del ignored_label   # only the initial value of cc.cls_label, overwritten by the seed's label (.cpp:12-18)
+    ball_query_idxs, start_len = _device_graph(ball_query_idxs, start_len)
     parts = _be().hierarchical_aggregation_parts(semantic_label, coord_shift, ball_query_idxs, start_len, batch_idxs,
                                                  bool(using_set_aggr_), point_num_avg.tolist(), radius_avg.tolist())
     for dst, src in zip((cluster_idxs_kept, cluster_offsets_kept, cluster_centers_kept), parts["kept"]):

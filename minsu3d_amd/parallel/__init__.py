@@ -26,7 +26,30 @@ def init_distributed():
         dist.init_process_group(backend, rank=rank, world_size=world)
     if os.environ.get("MS3D_SHARE_DEVICE") == "1":
         local = 0
+    if world > 1:
+        pin_rank_threads(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     return rank, local, world
+
+
+def pin_rank_threads(local_rank, local_world):
+    """Host side of one-process-per-GPU: every rank runs a main thread, the grouping helper thread and the loader's
+    collate, and torch's intra-op pool defaults to ALL cores of the node in every process.  Give each rank its own
+    contiguous slice of the cores this process may use (threads started later inherit the mask) and size the intra-op
+    pool to it, so that 8 ranks do not run 8 x nproc OpenMP threads against each other.  MS3D_PIN=0 leaves both alone.
+    -> the list of cores of this rank (None when nothing was changed)"""
+    if os.environ.get("MS3D_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(per, 16)))      # the host work of a step is a few small torch CPU ops
+    return mine
 
 
 def shard_scene_seeds(step, scenes_per_rank, rank, world_size):

@@ -39,3 +39,28 @@ def test_driver_launch_line_on_gloo(world):
     # value = scenes of ALL ranks / max-over-ranks time
     assert abs(rec["value"] - world * 1 * 2 / (rec["ms_per_step"] * 2 / 1000.0)) < 1e-2 * rec["value"]
     assert rec["step_ms"]["min"] <= rec["step_ms"]["median"] <= rec["step_ms"]["max"]
+
+
+def test_ranks_get_disjoint_core_slices():
+    """8 ranks x (main + helper + loader threads) + torch's intra-op pools must not fight for the same cores: each rank
+    pins itself to its own slice of the cores the process may use (parallel.pin_rank_threads)"""
+    code = ("import os, sys, json; sys.path.insert(0, %r)\n"
+            "from minsu3d_amd.parallel import pin_rank_threads\n"
+            "import torch\n"
+            "r = pin_rank_threads(int(sys.argv[1]), int(sys.argv[2]))\n"
+            "print(json.dumps([r, sorted(os.sched_getaffinity(0)), torch.get_num_threads()]))\n" % ROOT)
+    allowed = sorted(os.sched_getaffinity(0))
+    world = 4 if len(allowed) >= 4 else len(allowed)
+    if world < 2:
+        pytest.skip("one core")
+    seen = []
+    for rank in range(world):
+        out = subprocess.run([sys.executable, "-c", code, str(rank), str(world)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        mine, mask, nthreads = json.loads(out.stdout.strip().splitlines()[-1])
+        assert mine == mask and len(mine) == len(allowed) // world and 1 <= nthreads <= len(mine)
+        seen.append(set(mine))
+    assert all(a.isdisjoint(b) for i, a in enumerate(seen) for b in seen[i + 1:])
+    out = subprocess.run([sys.executable, "-c", code, "0", "4"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, MS3D_PIN="0"))
+    assert json.loads(out.stdout.strip().splitlines()[-1])[0] is None

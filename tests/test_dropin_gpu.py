@@ -67,6 +67,37 @@ def test_pointgroup_call_sequence(OPS, oracle):
     assert not a.is_cuda and torch.equal(a, cluster_idxs) and torch.equal(o, cluster_offsets)
 
 
+def test_host_round_trip_reuses_the_device_graph(OPS, oracle):
+    """model/pointgroup.py:43-55 verbatim data flow: ball query on the GPU, `.cpu()` of both results, clustering on the
+    HOST tensors.  The drop-in module recognises the host copies of its own last results and clusters the device
+    originals (no upload of the neighbour list); a host tensor that differs is uploaded and clustered as given."""
+    xyz, b, bo, sem = _scene(4, n=30000, B=2)
+    idx, start_len, _ = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
+                                   torch.from_numpy(bo).cuda(), 0.05, 40)
+    widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.05)
+    idx_cpu, sl_cpu = idx.cpu(), start_len.cpu()
+    assert np.array_equal(idx_cpu.numpy(), widx)
+    hits0 = list(OPS._REUSE_HITS)
+    out = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
+    OPS.pg_bfs_cluster(torch.from_numpy(sem), idx_cpu, sl_cpu, out[0], out[1], len(sem), 30)
+    assert OPS._REUSE_HITS[0] == hits0[0] + 1 and OPS._REUSE_HITS[1] == hits0[1]     # device copies taken
+    want = oracle.pg_bfs_cluster(sem, widx, wsl, 30)
+    assert np.array_equal(out[0].numpy(), want[0].reshape(-1, 2)) and np.array_equal(out[1].numpy(), want[1])
+    # host tensors that are NOT the remembered result: same sizes, one sampled entry changed -> not taken for it
+    g = OPS._GRAPHS[0]
+    other = idx_cpu.clone()
+    other[int(g["pos_idx"][7])] += 1
+    a_, b_ = OPS._device_graph(other, sl_cpu)
+    assert a_ is other and b_ is sl_cpu and OPS._REUSE_HITS[1] == hits0[1] + 1
+    # ... and a graph of another ball query (the oracle's, smaller radius) is uploaded and clustered as given
+    widx2, wsl2 = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
+    out2 = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
+    OPS.pg_bfs_cluster(torch.from_numpy(sem), torch.from_numpy(widx2), torch.from_numpy(wsl2), out2[0], out2[1], len(sem), 10)
+    assert OPS._REUSE_HITS[1] == hits0[1] + 2 and OPS._REUSE_HITS[0] == hits0[0] + 1
+    want2 = oracle.pg_bfs_cluster(sem, widx2, wsl2, 10)
+    assert np.array_equal(out2[0].numpy(), want2[0].reshape(-1, 2)) and np.array_equal(out2[1].numpy(), want2[1])
+
+
 def test_softgroup_call_sequence(OPS, oracle):
     """functions/softgroup_ops.py:18-30: outputs are `ball_query_idxs.new()` (empty), the class means a CPU float tensor"""
     xyz, b, bo, _ = _scene(1, n=8000, B=1)

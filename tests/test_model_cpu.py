@@ -139,6 +139,58 @@ def test_ddp_world_size_2_gloo(tmp_path):
     assert res[0][3] and res[1][3]                     # gradients identical after the all-reduce
 
 
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from minsu3d_amd import backend
+    from minsu3d_amd.parallel import sync_buffers
+    from oracle.oracle_backend import OracleBackend
+    backend.set_backend(OracleBackend())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = build_model(seed=0)                      # same parameters on both ranks
+    model.train()
+    batch = small_batch((10 + 2 * rank, 11 + 2 * rank))          # different scenes -> different BatchNorm statistics
+    with torch.no_grad():
+        model(batch)
+        if rank == 1:
+            model(batch)                             # ... and a different number of batches seen
+    bn = model.backbone.unet[1].blocks.block0.conv_branch[0].bn
+    mine = (bn.running_mean.clone(), bn.running_var.clone())
+    sync_buffers(model)
+    after = (bn.running_mean.clone(), bn.running_var.clone(), int(model.state_dict()[
+        "backbone.unet.1.blocks.block0.conv_branch.0.bn.num_batches_tracked"]))
+    # evaluation with the synchronised statistics gives the same numbers on every rank for the same scene
+    model.eval()
+    with torch.no_grad():
+        out = model(small_batch((20, 21)))
+    q.put((rank, [t.tolist() for t in mine], [t.tolist() for t in after[:2]], after[2], float(out["semantic_scores"].sum())))
+    dist.destroy_process_group()
+
+
+def test_sync_buffers_gives_every_rank_rank0_statistics():
+    """the reference runs Lightning DDP with torch's default broadcast_buffers=True (rank 0's BatchNorm running
+    statistics reach the other ranks at every forward); here the buffers are left alone during training and
+    sync_buffers() broadcasts rank 0's before validation / checkpoints (parallel/__init__.py): after it, rank 1
+    evaluates with rank 0's statistics and batch counter"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, mine0, after0, n0, s0), (_, mine1, after1, n1, s1) = res
+    assert mine0 != mine1                              # the ranks had diverged
+    assert after0 == mine0 and after1 == mine0         # everybody holds rank 0's statistics now
+    assert n0 == n1 == 1                               # ... and rank 0's counter (rank 1 had seen 2 batches)
+    assert s0 == s1
+
+
 def _build(name, seed=0):
     from minsu3d_amd.config import load_config
     import minsu3d_amd.model as M

@@ -39,3 +39,25 @@ for name, P, ma in (("orig", xyz, 50), ("shift", sh, 300)):
         wi, wo = O.pg_bfs_cluster(semfg.cpu().numpy(), widx, wsl, 50)
         assert np.array_equal(co.cpu().numpy(), wo) and np.array_equal(ci.cpu().numpy().reshape(-1, 2), wi.reshape(-1, 2)), "bfs differs"
         print(f"{name}: bit-exact vs oracle")
+
+
+# the reference's own data flow (pointgroup.py:43-55): ball query, `.cpu()` of the neighbour lists, clustering on the host
+# tensors through the drop-in COMMON_OPS module, clusters back to the device -- with and without the module's reuse of the
+# device copies (MS3D_DROPIN_REUSE)
+import minsu3d_amd.dropin as dropin
+dropin.install()
+import COMMON_OPS
+for reuse in ("1", "0"):
+    os.environ["MS3D_DROPIN_REUSE"] = reuse
+    COMMON_OPS._GRAPHS.clear()
+
+    def route():
+        n = sh.size(0)
+        idx = torch.zeros(n * 300, dtype=torch.int32, device=dev); sl = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        na = COMMON_OPS.ballquery_batch_p(sh, bi, bo, idx, sl, n, 300, 0.03)
+        ci, co = torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)
+        COMMON_OPS.pg_bfs_cluster(semfg.cpu(), idx[:na].cpu(), sl.cpu(), ci, co, n, 50)
+        return ci.long().to(dev), co.to(dev)
+    for _ in range(3): route()
+    ms, _ = timed(route, max(args.reps // 2, 6))
+    print(f"zero-edit route (shifted): ball query + .cpu() + COMMON_OPS.pg_bfs_cluster + .to(device), reuse={reuse}: {ms:.2f} ms")
