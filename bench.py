@@ -9,7 +9,7 @@
 
 Rank 0 prints ONE JSON line.
 
-`roofline`: measured live with HIP events on a sample of the timed steps (every 10th; an event pair costs host time).
+`roofline`: measured live with HIP events on a sample of the timed steps (one in 20: ~520 event records cost a step ~8 ms).
 The events are recorded INSIDE the library calls, immediately around each kernel, on the stream it is launched on.
 The object describes the dominant kernel family of the step -- ALL sparse-convolution launches (forward,
 backward-data, backward-weight: the SURVEY 8d / BASELINE.md figure, sum over the layers of
@@ -48,7 +48,7 @@ from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp  
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 MFMA (v_mfma_f32_16x16x4_f32), same guide / SURVEY 8d
-SAMPLE_EVERY = 10          # every 10th timed step carries the kernel events
+SAMPLE_EVERY = 20          # one timed step in 20 carries the kernel events (a sampled step costs ~8 ms of event records)
 
 
 def make_batch(seeds, device, scene_kwargs=None, offset_noise=0.04):
@@ -313,7 +313,7 @@ def main(argv=None):
     marks[0].record()
     for i in range(args.steps):
         if timer is not None:
-            timer.sampling = i % SAMPLE_EVERY == SAMPLE_EVERY // 2
+            timer.sampling = (i % SAMPLE_EVERY == SAMPLE_EVERY // 2) or (args.steps <= SAMPLE_EVERY // 2 and i == args.steps - 1)
             n_sampled += int(timer.sampling)
         loss = train_step(model, ddp, opt, batches[i % args.pool], batches[(i + 1) % args.pool])
         marks[i + 1].record()

@@ -292,6 +292,11 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
                                void *ev_start /* hipEvent_t or NULL: around the backward-data kernel */, void *ev_stop,
                                void *ev_wg_start /* hipEvent_t or NULL: around the backward-weight kernels */, void *ev_wg_stop,
+                               float *ws_wgrad /* slab workspace of the second stream (ms3d_spconv_layer_ws_floats) or NULL */,
+                               ms3d_stream_t wgrad_stream /* NULL: backward-weight on `stream`; else it runs on this
+                                                             stream beside the backward-data chain */,
+                               int join /* 1: `stream` waits for the backward-weight before the call returns control
+                                           of it; 0: the caller joins the streams before dW is read */,
                                ms3d_stream_t stream);
 
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */

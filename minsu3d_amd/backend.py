@@ -7,6 +7,7 @@ the same method surface via `set_backend` (e.g. the oracle-backed one in oracle/
 nothing in this package imports the oracle.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -56,6 +57,7 @@ class _Workspace:
 
 _POOL = None
 _SIDE = {}
+_WGRAD = {}
 
 
 def worker():
@@ -66,6 +68,14 @@ def worker():
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ms3d-side")
     return _POOL
+
+
+def wgrad_stream(device):
+    """the stream the backward-weight kernels run on beside the backward-data chain (conv_layer_backward)"""
+    s = _WGRAD.get(device)
+    if s is None:
+        s = _WGRAD[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def side_stream(device):
@@ -369,7 +379,8 @@ def _p(t):
 _VP, _I = C.c_void_p, C.c_int
 _FAST_ARGTYPES = {
     "ms3d_spconv_layer_forward": [_VP] * 3 + [_I] * 5 + [_VP] * 2 + [_I] + [_VP] * 5 + [_VP] * 2 + [_VP] * 2 + [_VP],
-    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 4 + [_VP],
+    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 4 +
+                                  [_VP, _VP, _I, _VP],
     "ms3d_bn_finalize": [_VP, _I, C.c_long, _I, C.c_float, C.c_float] + [_VP] * 4 + [_VP] * 4 + [_VP],
 }
 
@@ -749,14 +760,51 @@ class _HipEngine:
         ev0, ev1 = tok if tok is not None else (None, None)
         tok = timer.conv("wgrad", K, cin, cout, nbr_fwd, vout) if timer is not None else None
         ev2, ev3 = tok if tok is not None else (None, None)
+        mode = self.wgrad_stream_mode()
+        side = wgrad_stream(dev) if mode else None
+        ws2 = self.ws.get("layer_wgrad", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev) \
+            if side is not None else None
         _lib.check(self._fast("ms3d_spconv_layer_backward")(
             _p(x), _p(dy), _p(wf_buf), _p(nbr_fwd), _p(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _p(bn["scale"] if has_bn else None), _p(bn["shift"] if has_bn else None),
             _p(bn["mean"] if has_bn else None), _p(bn["invstd"] if has_bn else None),
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
             _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
-            _p(plb[1]), ev0, ev1, ev2, ev3, _lib.stream_handle()), "ms3d_spconv_layer_backward")
+            _p(plb[1]), ev0, ev1, ev2, ev3, _p(ws2), side.cuda_stream if side is not None else None,
+            int(mode == 1), _lib.stream_handle()), "ms3d_spconv_layer_backward")
+        if mode == 2:
+            # the second stream runs free until the end of the backward pass: the allocator must not hand x / dy to
+            # somebody else while it still reads them, and the pass ends with the join
+            x.record_stream(side); dy.record_stream(side); dW.record_stream(side)
+            self._queue_wgrad_join(side)
         return (dx if need_dx else None), dgb, dW
+
+    def wgrad_stream_mode(self):
+        """MS3D_WGRAD_STREAM: 0 (default) backward-weight on the caller's stream; 1: on a second stream, joined at the
+        end of every layer's backward (safe under DistributedDataParallel, whose gradient hooks order only against the
+        caller's stream); 2: joined once, at the end of the backward pass (single process).
+        Measured (profiles/r03_wgrad_stream_sweep.txt, one MI355X, 40 steps): HAIS 81.5 -> 83.7 (mode 1) -> 85.0 scenes/s
+        (mode 2); PointGroup unchanged within its run-to-run noise (169-175 in every mode).  The two streams' kernels
+        slow each other down (summed kernel time of the backward pass 11.3 -> 15.2 ms on PointGroup for a span that
+        shrinks 12.8 -> 12.6 ms), so the per-kernel durations the roofline is computed from get worse while the step
+        gets slightly better: off by default, a throughput knob for the m = 32 models."""
+        m = self.__dict__.get("_wgrad_mode")
+        if m is None:
+            m = self._wgrad_mode = int(os.environ.get("MS3D_WGRAD_STREAM", "0"))
+        return m
+
+    def _queue_wgrad_join(self, side):
+        if self.__dict__.get("_wgrad_join_queued"):
+            return
+
+        def join():
+            self._wgrad_join_queued = False
+            torch.cuda.current_stream().wait_stream(side)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join)
+            self._wgrad_join_queued = True
+        except RuntimeError:            # not inside a backward pass (a direct call): join now
+            join()
 
     def conv_backward_weight(self, x, dout, nbr, vout, K, cin, cout, pre=None, pre_relu=False):
         x = self._dev(x); dout = self._dev(dout)

@@ -22,6 +22,7 @@
 // Backward-weight is a second kernel: dW[k] = sum_i act(in[nbr[k][i]])^T dout[i] on the same MFMA, rows as
 // the reduction dimension, several offsets per wave sharing the dout fragment.
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 #include "../../include/minsu3d_hip.h"
 
@@ -2325,26 +2326,67 @@ float ms3d_event_elapsed_ms(void *start, void *stop)
 //   s1s2 = (sum dz, sum dz*xhat)  = (dbeta, dgamma)            -> dgb [2][Cin]
 //   dx   = scale * (dz - s1/V - xhat*s2/V)  (training)  or  scale * dz  (eval)
 //   dW   = sum_i act(x[nbr])^T dy  through per-chunk slabs in `ws`
+// events that order the two streams of ms3d_spconv_layer_backward (no timing; re-recorded round robin: a wait that was
+// already issued keeps the state it captured)
+static hipEvent_t order_event()
+{
+    static hipEvent_t pool[256];
+    static bool ready[256];
+    static std::atomic<unsigned> next{0};
+    const unsigned i = next.fetch_add(1) & 255u;
+    if (!ready[i]) {
+        if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        ready[i] = true;
+    }
+    return pool[i];
+}
+
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
                                int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *ol_fwd_kt_start,
                                const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
-                               void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop, ms3d_stream_t stream)
+                               void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop, float *ws_wgrad,
+                               ms3d_stream_t wgrad_stream, int join, ms3d_stream_t stream)
 {
     const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
     const float *wft = wf_buf + 2 * nwf, *wfts = wf_buf + 3 * nwf;
     const bool bn = scale != nullptr;
     int rc;
+    // Backward-weight needs x and dy only, not the backward-data result: with a second stream (and its own slab
+    // workspace) it runs BESIDE the backward-data convolution and the three small kernels of the BatchNorm-backward chain
+    // behind it -- ~250 launches of ~5 us per step that otherwise leave the chip idle between two convolutions.
+    hipStream_t main = (hipStream_t)stream, side = wgrad_stream ? (hipStream_t)wgrad_stream : main;
+    float *slabs;
+    hipEvent_t done = nullptr;
+    auto run_wgrad = [&]() -> int {
+        if (ev_wg_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_start, side));
+        int r = ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs,
+                                            ol_fwd_kt_start, ol_fwd_entries, (ms3d_stream_t)side);
+        if (ev_wg_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_stop, side));
+        return r;
+    };
+    if (side != main) {
+        if (!ws_wgrad) return MS3D_E_WORKSPACE;
+        slabs = ws_wgrad;
+        hipEvent_t ready = order_event();
+        done = order_event();
+        if (!ready || !done) return MS3D_E_INTERNAL;
+        MS3D_CHECK(hipEventRecord(ready, main));          // dy (and the lists built on this stream) are complete here
+        MS3D_CHECK(hipStreamWaitEvent(side, ready, 0));
+        rc = run_wgrad();
+        if (rc) return rc;
+        MS3D_CHECK(hipEventRecord(done, side));
+    }
     // optional HIP events bracketing ONLY the backward-data convolution kernel (bench.py roofline)
-    if (ev_start && (need_dx || bn)) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
+    if (ev_start && (need_dx || bn)) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, main));
     if (need_dx || bn) {
         if (!bn) {
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts,
                                      stream);
             if (rc) return rc;
-            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, main));
             ev_stop = nullptr;
         } else {
             if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
@@ -2353,7 +2395,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
                                      mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts, stream);
             if (rc) return rc;
-            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+            if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, main));
             ev_stop = nullptr;
             rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
             if (rc) return rc;
@@ -2367,14 +2409,15 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             }
         }
     }
+    if (side != main) {
+        // join = 1: everything queued on `stream` after this call sees dW (what a gradient hook of a data-parallel
+        // wrapper needs); join = 0: the caller joins the two streams itself before dW is read
+        if (join) MS3D_CHECK(hipStreamWaitEvent(main, done, 0));
+        return 0;
+    }
     const int pb0 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 0), pb1 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 1);
-    float *slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
-    // second optional event pair: the backward-weight kernel and its slab reduction
-    if (ev_wg_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_start, (hipStream_t)stream));
-    rc = ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs, ol_fwd_kt_start,
-                                     ol_fwd_entries, stream);
-    if (ev_wg_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_stop, (hipStream_t)stream));
-    return rc;
+    slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
+    return run_wgrad();
 }
 
 }  // extern "C"

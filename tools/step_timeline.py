@@ -43,6 +43,14 @@ for name, a, b in marks:
         last = max(last, e[1])
     print(f"{name:40s} span {span / 1e6:7.3f} ms  launches {len(seg):4d}  no-kernel {idle / 1e6:6.3f} ms  kernel ms by queue: "
           + ", ".join(f"q{q}={t / 1e3:.2f}" for q, t in sorted(per_q.items())))
+if '--top' in sys.argv:
+    for name, a, b in marks:
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for e in step[a:b]:
+            g = agg[e[2]]; g[0] += 1; g[1] += (e[1] - e[0]) / 1e3
+        print(f"== {name}: kernel time {sum(v[1] for v in agg.values()) / 1e3:.2f} ms")
+        for k_, (n_, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+            print(f"   {k_:46s} {n_:4d}  {us / 1e3:7.3f} ms  {us / n_:7.1f} us")
 if '--window' in sys.argv and i_bq is not None:
     a, b = max(i_bq - 3, 0), min(i_pv + 12, len(step))
     last = step[a][0]
