@@ -250,10 +250,14 @@ int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int 
 /* 1 if a layer of this shape can be served by the weight-streaming kernel (then its descriptor in
  * ms3d_spconv_prep_weights_multi must ask for the streamed images: field `stream`) */
 int ms3d_spconv_wants_stream_image(int K, int Cin, int Cout);
+/* what the aux slot (2n floats) behind each weight image of a layer buffer holds: 0 nothing, 1 the streamed f32 image,
+ * 2 the three-piece bf16 image (wide square layers).  Layer buffer = [image n | aux 2n | transposed image n | aux 2n],
+ * n = ms3d_spconv_wf_floats(K, Cin, Cout). */
+int ms3d_spconv_aux_kind(int K, int Cin, int Cout);
 /* Both images of n layers in ONE launch (a U-Net re-lays ~90 weight tensors per step, ~5 us of dispatch each).
  * descs: device array of n 48-byte records {const float *W; float *wf; float *wft; int K, Cin, Cout, mirror_bwd,
- * block_begin, stream}, stream = ms3d_spconv_wants_stream_image(K, Cin, Cout), block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum.
- * wf and wft each have room for 2 * ms3d_spconv_wf_floats() floats: the image, then its streamed form. */
+ * block_begin, stream}, stream = ms3d_spconv_aux_kind(K, Cin, Cout), block_begin = running sum of ms3d_spconv_prep_blocks(K, Cin, Cout); total_blocks = the full sum.
+ * wf and wft each have room for 3 * ms3d_spconv_wf_floats() floats: the image, then its aux image (slot of 2n). */
 int ms3d_spconv_prep_blocks(int K, int Cin, int Cout);
 int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, ms3d_stream_t stream);
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,

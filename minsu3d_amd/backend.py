@@ -688,7 +688,7 @@ class _HipEngine:
 
     def wf_floats(self, K, cin, cout):
         """floats of a layer's weight buffer: forward and backward-data image, each followed by its streamed form"""
-        return 4 * self._geom("ms3d_spconv_wf_floats", K, cin, cout)
+        return 6 * self._geom("ms3d_spconv_wf_floats", K, cin, cout)    # [image | aux 2n | transposed image | aux 2n]
 
     def prep_weights_multi(self, layers):
         """layers: [(W [K,cin,cout] parameter, wf_buf, K, cin, cout, mirror_bwd)] -> both weight images of every layer in
@@ -706,9 +706,9 @@ class _HipEngine:
             begin = 0
             for i, (w, b, K, cin, cout, m) in enumerate(layers):
                 assert w.is_contiguous() and w.dtype == torch.float32 and b.numel() >= self.wf_floats(K, cin, cout)
-                rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * 2 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
+                rec[i] = (w.data_ptr(), b.data_ptr(), b.data_ptr() + 4 * 3 * self._geom("ms3d_spconv_wf_floats", K, cin, cout),
                           K, cin, cout, int(bool(m)), begin,
-                          int(self.lib.ms3d_spconv_wants_stream_image(int(K), int(cin), int(cout))))
+                          int(self.lib.ms3d_spconv_aux_kind(int(K), int(cin), int(cout))))
                 begin += self.lib.ms3d_spconv_prep_blocks(int(K), int(cin), int(cout))
             table = torch.from_numpy(rec.view(np.uint8).copy()).to(layers[0][0].device)
             cached = self._prep_table = (key, table, begin)

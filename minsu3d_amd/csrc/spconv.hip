@@ -45,6 +45,7 @@ struct ConvArgs {
     const float *in;         // [Vin, Cin]
     const float *wf;         // fragment-major weights
     const float *wfs;        // the same weights in streamed order (prep_weights_kernel) or null
+    const void *wfb;         // the three-piece bf16 image (write_bf3) or null
     const int *nbr;          // [K][Vout]
     float *out;              // [Vout, Cout]
     const float *pre_scale;  // [Cin] or null : a = max(0, x*scale + shift)
@@ -84,10 +85,48 @@ __device__ __forceinline__ long stream_slot(long o, int NBtot)
     return ((r * NBtot + nb) * 64 + lane) * 4 + t;
 }
 
+// ---- three-piece bf16 images (round 3) -----------------------------------------------------------------------
+// f32 MFMA runs at 1/16 of the bf16 rate on gfx950 and there is no xf32.  A float splits EXACTLY into three bf16
+// pieces (x = x0 + x1 + x2, 24 = 3 x 8 mantissa bits, each remainder computed in f32 without rounding), every
+// bf16 x bf16 product is exact in f32, and the six products down to 2^-16 -- x0w0, x0w1, x1w0, x1w1, x0w2, x2w0 --
+// carry a dot product to ~2^-23 relative: float32-grade results from v_mfma_f32_16x16x32_bf16 at 6 instructions per
+// 32 input channels instead of 8 f32 instructions of twice the issue time (2.7x less matrix-pipe time).
+// Image layout: Wb[(((k*NC32 + c32)*NB + nb)*3 + piece)*64 + lane][e]  (8 bf16 = 16 B per lane),
+//               lane = (j & 15) + 16*g holds W[k][c = 32*c32 + 8*g + e][j = 16*nb + (lane & 15)], e = 0..7
+// -- the B operand of the instruction for column block nb and 32-channel chunk c32, one ds_read_b128 per lane.
+// It lives in the AUX slot behind the f32 image (where rectangular layers keep their streamed image).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ inline bool bf3_dims_ok(int K, int Cin, int Cout)
+{
+    return K > 1 && Cin % 32 == 0 && Cout % 32 == 0 && Cin >= 64 && Cout >= 64 && Cin <= 256 && Cout <= 256;
+}
+
+__device__ __forceinline__ void split3(float v, __bf16 &h0, __bf16 &h1, __bf16 &h2)
+{
+    h0 = (__bf16)v;
+    const float r1 = v - (float)h0;   // exact
+    h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;  // exact
+    h2 = (__bf16)r2;
+}
+
+__device__ __forceinline__ void write_bf3(float *aux, int k, int c, int j, int Cin_e, int NB, float v)
+{
+    __bf16 *img = reinterpret_cast<__bf16 *>(aux);
+    const int NC32 = Cin_e >> 5, c32 = c >> 5, g = (c >> 3) & 3, e = c & 7, nb = j >> 4, jl = j & 15;
+    const size_t base = ((((size_t)k * NC32 + c32) * NB + nb) * 3) * 64 + (jl + 16 * g);
+    __bf16 h0, h1, h2;
+    split3(v, h0, h1, h2);
+    img[(base + 0) * 8 + e] = h0;
+    img[(base + 64) * 8 + e] = h1;
+    img[(base + 128) * 8 + e] = h2;
+}
+
 __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restrict__ wf, int K, int Cin_e, int Cout_e,
                                     int NCH, int NBtot, int transpose, int mirror, float *__restrict__ wf2, int NCH2,
-                                    int NBtot2, int mirror2, float *__restrict__ wfs, float *__restrict__ wfs2)
-{
+                                    int NBtot2, int mirror2, float *__restrict__ wfs, float *__restrict__ wfs2, int aux_kind)
+{   // aux_kind: 1 = wfs / wfs2 take the streamed f32 image, 2 = the three-piece bf16 image
     const long total = (long)K * NCH * 4 * NBtot * 64;
     if (wf2) {
         // second image in the same launch: the backward-data operator (transposed, Cin/Cout swapped)
@@ -103,7 +142,8 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
             const int ks = mirror2 ? (K - 1 - k) : k;
             const float v = (c < Cout_e && j < Cin_e) ? W[((size_t)ks * Cin_e + j) * Cout_e + c] : 0.f;
             wf2[o] = v;
-            if (wfs2) wfs2[stream_slot(o, NBtot2)] = v;
+            if (wfs2 && aux_kind == 1) wfs2[stream_slot(o, NBtot2)] = v;
+            if (wfs2 && aux_kind == 2 && c < Cout_e && j < Cin_e) write_bf3(wfs2, k, c, j, Cout_e, NBtot2, v);
         }
     }
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -120,7 +160,8 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
             v = transpose ? W[((size_t)ks * Cout_e + j) * Cin_e + c]   // original layout [K][Cout_e(=Cin_o)][Cin_e(=Cout_o)]
                           : W[((size_t)ks * Cin_e + c) * Cout_e + j];
         wf[o] = v;
-        if (wfs) wfs[stream_slot(o, NBtot)] = v;
+        if (wfs && aux_kind == 1) wfs[stream_slot(o, NBtot)] = v;
+        if (wfs && aux_kind == 2 && c < Cin_e && j < Cout_e) write_bf3(wfs, k, c, j, Cin_e, NBtot, v);
     }
 }
 
@@ -129,9 +170,9 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
 struct PrepDesc {
     const float *W;   // [K][Cin][Cout]
     float *wf, *wft;  // forward image, backward-data image (transposed, offsets mirrored if mirror_bwd);
-                      // each is followed by its streamed image: wf + n, wft + n  (n = ms3d_spconv_wf_floats)
+                      // each is followed by its aux image: wf + n, wft + n  (n = ms3d_spconv_wf_floats; slot of 2n)
     int K, Cin, Cout, mirror_bwd, block_begin;
-    int stream;       // also write the streamed images (only layers that can take spconv_fwd_pairstream_kernel read them)
+    int stream;       // aux images: 1 = streamed f32 (layers that can take spconv_fwd_pairstream_kernel), 2 = three-piece bf16
 };
 static_assert(sizeof(PrepDesc) == 48, "layout shared with the host-side descriptor table");
 
@@ -156,7 +197,8 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int c = 16 * ch + 4 * q + t, j = 16 * nb + jl;
         const float v = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
         d.wf[o] = v;
-        if (d.stream) d.wf[total + stream_slot(o, NB)] = v;
+        if (d.stream == 1) d.wf[total + stream_slot(o, NB)] = v;
+        if (d.stream == 2 && c < d.Cin && j < d.Cout) write_bf3(d.wf + total, k, c, j, d.Cin, NB, v);
     }
     {
         long r = o >> 6;
@@ -167,7 +209,8 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const int ks = d.mirror_bwd ? (d.K - 1 - k) : k;
         const float v = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
         d.wft[o] = v;
-        if (d.stream) d.wft[total + stream_slot(o, NCH)] = v;
+        if (d.stream == 1) d.wft[total + stream_slot(o, NCH)] = v;
+        if (d.stream == 2 && c < d.Cout && j < d.Cin) write_bf3(d.wft + total, k, c, j, d.Cout, NCH, v);
     }
 }
 
@@ -421,6 +464,159 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
         // each blockIdx.y owns its own columns; others stay zero and are summed away by the finalize kernel
         for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
     }
+}
+
+// ---- table walk on the three-piece bf16 image (wide square layers, Cin and Cout multiples of 32) ----------------
+// Same geometry and epilogue as spconv_fwd_kernel: a wave owns 16 output rows x NBT column blocks, the block's column
+// slice of the weights is staged through LDS in groups of G offsets.  Per offset and 32-channel chunk a lane gathers
+// the 8 channels [32*c32 + 8*(lane >> 4), +8) of its row (two 16-byte loads), applies the fused BatchNorm / ReLU,
+// splits the 8 floats into three bf16 pieces (exact) and issues six v_mfma_f32_16x16x32_bf16 per column block --
+// x0w0, x0w1, x1w0, x1w1, x0w2, x2w0 -- into the f32 accumulator: float32-grade (tests: 1e-6 against the f32 kernel).
+constexpr int OGB = 5;   // offsets per gather group: 10 x 16 B per lane in flight
+
+template <int NBT>
+__global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    const int l = lane_id(), g8 = l >> 4;
+    const int waves = blockDim.x >> 6;
+    const int nb0 = blockIdx.y * NBT;
+    const int NC32 = p.Cin >> 5;
+    uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][c32][nb][piece][lane] x 16 B
+    float *s_part = lds + (size_t)p.G * NC32 * NBT * 3 * 64 * 4;           // [2*Cout] when statistics are asked for
+    const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
+    const int slab = NBT * 3 * 64;                                          // uint4 per (offset, c32) in the LDS image
+    auto stage = [&](int k_lo, int cnt) {
+        const int rows = cnt * NC32;
+        for (int e = threadIdx.x; e < rows * slab; e += blockDim.x) {
+            const int r = e / slab, c = e - r * slab;
+            sW[e] = img[((size_t)(k_lo * NC32 + r) * p.NBtot + nb0) * 3 * 64 + c];
+        }
+    };
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) {
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    }
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (nblk % 8 != 0) vb = blockIdx.x;  // only remap when it is a bijection
+
+    // offsets [k_lo, k_hi) of one tile against the staged group that starts at offset g0
+    auto accumulate = [&](int g0, int k_lo, int k_hi, int my_row, f32x4 (&acc)[NBT]) {
+        const bool row_ok = my_row < p.Vout;
+        const int safe_row = row_ok ? my_row : 0;
+        for (int k0 = k_lo; k0 < k_hi; k0 += OGB) {
+            int idx[OGB];
+#pragma unroll
+            for (int u = 0; u < OGB; u++) {
+                const int k = min(k0 + u, k_hi - 1);
+                const int v = p.nbr[(size_t)k * p.Vout + safe_row];
+                idx[u] = v | ((row_ok && k0 + u < k_hi) ? 0 : -1);
+            }
+            bool any[OGB];
+#pragma unroll
+            for (int u = 0; u < OGB; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
+            for (int c32 = 0; c32 < NC32; c32++) {
+                const int c0 = 32 * c32 + 8 * g8;
+                f32x4 lo[OGB], hi[OGB];
+#pragma unroll
+                for (int u = 0; u < OGB; u++) {     // unconditional, clamped (a branch around a gather drains the counter)
+                    const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
+                    lo[u] = *reinterpret_cast<const f32x4 *>(row);
+                    hi[u] = *reinterpret_cast<const f32x4 *>(row + 4);
+                }
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, b0 = s0, b1 = s0;
+                if (p.pre_scale) {
+                    s0 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0); s1 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0 + 4);
+                    b0 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0); b1 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0 + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < OGB; u++) {
+                    if (!any[u]) continue;
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { v[t] = lo[u][t]; v[4 + t] = hi[u][t]; }
+                    if (p.pre_scale) {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float x0 = fmaf(v[t], s0[t], b0[t]), x1 = fmaf(v[4 + t], s1[t], b1[t]);
+                            v[t] = p.pre_relu ? fmaxf(x0, 0.f) : x0;
+                            v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
+                        }
+                    }
+                    const int keep = ~(idx[u] >> 31);   // absent neighbour (idx < 0) contributes nothing
+                    bf16x8 a0, a1, a2;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        __bf16 h0, h1, h2;
+                        split3(__int_as_float(__float_as_int(v[e]) & keep), h0, h1, h2);
+                        a0[e] = h0; a1[e] = h1; a2[e] = h2;
+                    }
+                    const uint4 *w = sW + (size_t)((k0 - g0 + u) * NC32 + c32) * slab + l;
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) {
+                        const uint4 r0 = w[(nb * 3 + 0) * 64], r1 = w[(nb * 3 + 1) * 64], r2 = w[(nb * 3 + 2) * 64];
+                        const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&r0), w1 = *reinterpret_cast<const bf16x8 *>(&r1),
+                                     w2 = *reinterpret_cast<const bf16x8 *>(&r2);
+                        // smallest terms first
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w0, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w2, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w1, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc[nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    if (p.G >= p.K) {
+        stage(0, p.K);
+        __syncthreads();
+        const int total_waves = nblk * waves;
+        const int chunk = (p.ntiles + total_waves - 1) / total_waves;
+        const int wglobal = vb * waves + wave_id();
+        const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
+        for (int tile = t_begin; tile < t_end; tile++) {
+            const int row0 = tile * 16;
+            f32x4 acc[NBT];
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accumulate(0, 0, p.K, row0 + (l & 15), acc);
+            store_tile<NBT>(p, row0, nb0, acc, s_part);
+        }
+    } else {
+        const int tile = vb * waves + wave_id();
+        const int row0 = tile * 16;
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < p.K; g0 += p.G) {
+            const int gn = min(p.G, p.K - g0);
+            __syncthreads();
+            stage(g0, gn);
+            __syncthreads();
+            if (tile < p.ntiles) accumulate(g0, g0, g0 + gn, row0 + (l & 15), acc);
+        }
+        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
+    }
+    if (with_partial) {
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT>
+int launch_fwd_bf3(const ConvArgs &p, dim3 grid, int threads, size_t lds, hipStream_t stream)
+{
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_bf3_kernel<NBT>);
+    MS3D_CHECK(attr);
+    spconv_fwd_bf3_kernel<NBT><<<grid, threads, lds, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
 }
 
 // Small levels (a few hundred to a few thousand rows at the bottom of the U-Net, 64..224 channels): the weight image
@@ -1243,6 +1439,125 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     }
 }
 
+// Backward-weight on three-piece bf16 operands (wide layers; see the image comment at write_bf3 for the arithmetic).
+// The reduction dimension of dW[k] = sum_rows act(in[nbr_k(row)])^T dout[row] is the ROW: v_mfma_f32_16x16x32_bf16 takes
+// 32 rows per instruction (the f32 instruction 4), lane (channel cl, group q) holding rows r0 + 8q .. 8q + 7 of its
+// channel / column.  Both operands are split on the fly (exactly) into three bf16 pieces and the six products down to
+// 2^-16 are accumulated in f32: 6 instructions per 32 rows instead of 8 f32 instructions of twice the issue time.
+// Same grid, slabs and cross-wave reduction as spconv_wgrad_kernel.
+template <int KG, int NBT>
+__global__ __launch_bounds__(256) void spconv_wgrad_bf3_kernel(WgradArgs p)
+{
+    __shared__ float s_red[4 * NBT * 256];
+    const int l = lane_id(), q = l >> 4, cl = l & 15;
+    const int k0 = blockIdx.y * KG;
+    const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A elements
+    const bool c_ok = c < p.Cin;
+    const int c_safe = c_ok ? c : 0;
+    const float sc = (p.pre_scale && c_ok) ? p.pre_scale[c] : 1.f;
+    const float sh = (p.pre_scale && c_ok) ? p.pre_shift[c] : 0.f;
+    f32x4 acc[KG][NBT];
+#pragma unroll
+    for (int a = 0; a < KG; a++)
+#pragma unroll
+        for (int b = 0; b < NBT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r_begin = blockIdx.x * p.rows_per_block;
+    const int r_end = min(p.Vout, r_begin + p.rows_per_block);
+    const int nw = blockDim.x >> 6;
+    for (int r0 = r_begin + wave_id() * 32; r0 < r_end; r0 += 32 * nw) {
+        const int rbase = r0 + 8 * q;           // this lane's 8 rows
+        // table entries of all KG offsets and the dout values of all column blocks: one round trip
+        int idx[KG][8];
+#pragma unroll
+        for (int kk = 0; kk < KG; kk++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int row = rbase + e;
+                const bool ok = row < r_end;
+                const int v = p.nbr[(size_t)min(k0 + kk, p.K - 1) * p.Vout + (ok ? row : r_begin)];
+                idx[kk][e] = v | ((k0 + kk < p.K && ok) ? 0 : -1);
+            }
+        bf16x8 bw[NBT][3];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) {
+            const int j = 16 * nb + cl;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int row = rbase + e;
+                const bool ok = row < r_end && j < p.Cout;
+                const float x = p.dout[(size_t)(row < r_end ? row : r_begin) * p.Cout + (j < p.Cout ? j : 0)];
+                v[e] = __int_as_float(__float_as_int(x) & (ok ? -1 : 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                __bf16 h0, h1, h2;
+                split3(v[e], h0, h1, h2);
+                bw[nb][0][e] = h0; bw[nb][1][e] = h1; bw[nb][2][e] = h2;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KG; kk++) {
+            int any = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) any |= ~idx[kk][e];          // sign bit set <=> some entry >= 0
+            if (__ballot(any < 0) == 0ull) continue;                  // no row of the 32 has this neighbour
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) a[e] = p.in[(size_t)max(idx[kk][e], 0) * p.Cin + c_safe];
+            bf16x8 a0, a1, a2;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float v = a[e];
+                if (p.pre_scale) {
+                    v = fmaf(v, sc, sh);
+                    if (p.pre_relu) v = fmaxf(v, 0.f);
+                }
+                v = __int_as_float(__float_as_int(v) & ~(idx[kk][e] >> 31) & (c_ok ? -1 : 0));
+                __bf16 h0, h1, h2;
+                split3(v, h0, h1, h2);
+                a0[e] = h0; a1[e] = h1; a2[e] = h2;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) {
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bw[nb][0], acc[kk][nb], 0, 0, 0);
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][2], acc[kk][nb], 0, 0, 0);
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw[nb][1], acc[kk][nb], 0, 0, 0);
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw[nb][0], acc[kk][nb], 0, 0, 0);
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][1], acc[kk][nb], 0, 0, 0);
+                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][0], acc[kk][nb], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
+#pragma unroll
+    for (int kk = 0; kk < KG; kk++) {
+        const int k = k0 + kk;
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_red[(wave_id() * NBT + nb) * 256 + r * 64 + l] = acc[kk][nb][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < NBT * 256; e += blockDim.x) {
+            float v = 0.f;
+            for (int w = 0; w < nw; w++) v += s_red[w * NBT * 256 + e];
+            const int nb = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+            const int ci = blockIdx.z * 16 + 4 * (ln >> 4) + r, j = 16 * nb + (ln & 15);
+            if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
+        }
+    }
+}
+
+template <int KG, int NBT>
+int launch_wgrad_bf3(const WgradArgs &p, int nblk_rows, hipStream_t stream)
+{
+    dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
+    spconv_wgrad_bf3_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // dW[e] = sum over row chunks of partial[b][e].  Block = 16 elements x 16 slab lanes: lane j sums slabs j, j+16, ...
 // and the 16 lane sums are combined in lane order -> fixed order, deterministic; 16x the threads of one-thread-per-
 // element (the slab walk is latency-bound: 251 slabs took 21 us).
@@ -1781,23 +2096,28 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
     const int NCH = ms3d_divup(Cin_eff, 16), NBtot = ms3d_divup(Cout_eff, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64;
     prep_weights_kernel<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
-        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror, nullptr, 0, 0, 0, wf_stream, nullptr);
+        W, wf, K, Cin_eff, Cout_eff, NCH, NBtot, transpose, mirror, nullptr, 0, 0, 0, wf_stream, nullptr, 1);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
 
 // forward image wf (W[K][Cin][Cout]) and backward-data image wft (W^T, optionally offset-mirrored) in ONE launch
-int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
-                                  float *wf_stream, float *wft_stream, ms3d_stream_t stream)
+static int prep_weights_pair_impl(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
+                                  float *wf_aux, float *wft_aux, int aux_kind, hipStream_t stream)
 {
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int NCH2 = ms3d_divup(Cout, 16), NBtot2 = ms3d_divup(Cin, 16);
     const long total = (long)K * NCH * 4 * NBtot * 64, total2 = (long)K * NCH2 * 4 * NBtot2 * 64;
     const long m = total > total2 ? total : total2;
-    prep_weights_kernel<<<(int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(
-        W, wf, K, Cin, Cout, NCH, NBtot, 0, 0, wft, NCH2, NBtot2, mirror_bwd, wf_stream, wft_stream);
+    prep_weights_kernel<<<(int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048), 256, 0, stream>>>(
+        W, wf, K, Cin, Cout, NCH, NBtot, 0, 0, wft, NCH2, NBtot2, mirror_bwd, wf_aux, wft_aux, aux_kind);
     MS3D_LAUNCH_CHECK();
     return 0;
+}
+int ms3d_spconv_prep_weights_pair(const float *W, int K, int Cin, int Cout, int mirror_bwd, float *wf, float *wft,
+                                  float *wf_stream, float *wft_stream, ms3d_stream_t stream)
+{
+    return prep_weights_pair_impl(W, K, Cin, Cout, mirror_bwd, wf, wft, wf_stream, wft_stream, 1, (hipStream_t)stream);
 }
 
 // the same for n layers in one launch; descs = device array of {W, wf, wft, K, Cin, Cout, mirror_bwd, block_begin, 0}
@@ -2021,6 +2341,15 @@ int ms3d_spconv_wants_stream_image(int K, int Cin, int Cout)
     return (pairstream_layer_ok(K, Cin, Cout) || pairstream_layer_ok(K, Cout, Cin)) ? 1 : 0;
 }
 
+// what the aux slot behind a layer's weight images holds: 0 nothing, 1 the streamed f32 image (rectangular layers the
+// weight-streaming kernel may serve), 2 the three-piece bf16 image (wide square layers; MS3D_BF16X3=0 switches it off)
+int ms3d_spconv_aux_kind(int K, int Cin, int Cout)
+{
+    if (ms3d_spconv_wants_stream_image(K, Cin, Cout)) return 1;
+    static const bool on = [] { const char *e = getenv("MS3D_BF16X3"); return !e || atoi(e) != 0; }();
+    return (on && bf3_dims_ok(K, Cin, Cout)) ? 2 : 0;
+}
+
 int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0 && Vout >= pairlist_min_rows() && K > 1 && K <= 27; }
 
 // rows per tile of the pair list a forward / backward-data convolution of this shape walks: 0 = none (table walk /
@@ -2038,6 +2367,13 @@ int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pair
 }
 
 // out = conv(act(in)) [+ residual]; see ConvArgs.  wf from ms3d_spconv_prep_weights.
+static int spconv_forward_impl(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
+                               float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
+                               const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
+                               const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
+                               const float *bias, const int *pl_tile_start, const int *pl_entries, const float *wf_aux,
+                               int aux_kind, ms3d_stream_t stream_);
+
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
                         float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
                         const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
@@ -2045,11 +2381,25 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
                         const float *bias, const int *pl_tile_start, const int *pl_entries, const float *wf_stream,
                         ms3d_stream_t stream_)
 {
+    return spconv_forward_impl(in, wf, nbr, Vout, K, Cin, Cout, out, pre_scale, pre_shift, pre_relu, residual, bn_x, bn_scale,
+                               bn_shift, bn_mean, bn_invstd, bn_partial, out_stats, bias, pl_tile_start, pl_entries,
+                               wf_stream, wf_stream ? 1 : 0, stream_);
+}
+
+static int spconv_forward_impl(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,
+                               float *out, const float *pre_scale, const float *pre_shift, int pre_relu,
+                               const float *residual, const float *bn_x, const float *bn_scale, const float *bn_shift,
+                               const float *bn_mean, const float *bn_invstd, float *bn_partial, int out_stats,
+                               const float *bias, const int *pl_tile_start, const int *pl_entries, const float *wf_stream,
+                               int aux_kind, ms3d_stream_t stream_)
+{
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
     ConvArgs p;
     p.bias = bias;
     p.wfs = nullptr;
+    p.wfb = nullptr;
+    if (aux_kind != 1 && aux_kind != 2) wf_stream = nullptr;
     p.pl_tile_start = pl_tile_start; p.pl_entries = pl_entries;
     p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
@@ -2062,7 +2412,7 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
     dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
     if (g.stream) {
-        if (!wf_stream) return MS3D_E_UNSUPPORTED;  // the geometry (and the caller's partial buffer) assume this kernel
+        if (!wf_stream || aux_kind != 1) return MS3D_E_UNSUPPORTED;  // the geometry (and the caller's partial buffer) assume this kernel
         p.wfs = wf_stream;
 #define MS3D_PS(NBT_, CG_) \
     if (g.nbt == NBT_ && g.cg == CG_) return launch_fwd_pairstream<NBT_, CG_>(p, grid, g.threads, g.lds, stream);
@@ -2094,6 +2444,29 @@ int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vo
             case 8: return launch_fwd_small<8>(p, grid, g.threads, g.lds, aligned, stream);
         }
         return MS3D_E_UNSUPPORTED;
+    }
+    if (aux_kind == 2 && wf_stream && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2) {
+        // same grid as the f32 table walk (the statistics partials are sized for it); only the staged group shrinks:
+        // three bf16 pieces are 6 bytes per weight
+        const size_t per_offset = (size_t)(Cin / 32) * g.nbt * 3 * 1024;
+        const size_t extra = (bn_x != nullptr || p.out_stats) ? 2 * (size_t)Cout * sizeof(float) : 0;
+        int G = (int)((LDS_BUDGET - extra) / per_offset);
+        if (G > K) G = K;
+        const bool was_resident = g.G >= K;
+        if (G >= 1 && (!was_resident || G >= K)) {
+            p.wfb = wf_stream;
+            p.G = G;
+            const size_t lds = per_offset * G + extra;
+            switch (g.nbt) {
+                case 2: return launch_fwd_bf3<2>(p, grid, g.threads, lds, stream);
+                case 3: return launch_fwd_bf3<3>(p, grid, g.threads, lds, stream);
+                case 4: return launch_fwd_bf3<4>(p, grid, g.threads, lds, stream);
+                case 5: return launch_fwd_bf3<5>(p, grid, g.threads, lds, stream);
+                case 6: return launch_fwd_bf3<6>(p, grid, g.threads, lds, stream);
+                case 7: return launch_fwd_bf3<7>(p, grid, g.threads, lds, stream);
+                case 8: return launch_fwd_bf3<8>(p, grid, g.threads, lds, stream);
+            }
+        }
     }
     switch (g.nbt) {
         case 1: return launch_fwd<1>(p, grid, g.threads, g.lds, aligned, stream);
@@ -2155,6 +2528,13 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     }
     const int nb = p.NBtot;
     if (nb > 14) return MS3D_E_UNSUPPORTED;
+    static const bool bf3_on = [] { const char *e = getenv("MS3D_BF16X3"); return !e || atoi(e) != 0; }();
+    static const bool bf3_wgrad = [] { const char *e = getenv("MS3D_BF16X3_WGRAD"); return e && atoi(e) != 0; }();   // experiment: measured slower
+    const bool bf3 = bf3_wgrad && !use_list && bf3_on && K > 1 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin % 16 == 0 && Cout % 16 == 0;
+    if (bf3) {   // a workgroup's four waves take 32 rows each per trip
+        p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 128) * 128;
+        nblk = ms3d_divup(Vout, p.rows_per_block);
+    }
     int rc;
     if (use_list) {
         // two input chunks per workgroup when Cin allows (entries and dout rows fetched once for both)
@@ -2163,6 +2543,16 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
            : nb == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
            : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
+        if (rc) return rc;
+        launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    }
+    if (bf3) {
+        // wide layers: three-piece bf16 operands (f32-grade), 2.7x less matrix-pipe time
+        rc = nb == 3 ? launch_wgrad_bf3<4, 3>(p, nblk, stream) : nb == 4 ? launch_wgrad_bf3<4, 4>(p, nblk, stream)
+           : nb == 5 ? launch_wgrad_bf3<4, 5>(p, nblk, stream) : nb == 6 ? launch_wgrad_bf3<3, 6>(p, nblk, stream)
+           : nb == 7 ? launch_wgrad_bf3<2, 7>(p, nblk, stream) : launch_wgrad_bf3<2, 8>(p, nblk, stream);
         if (rc) return rc;
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
         MS3D_LAUNCH_CHECK();
@@ -2292,15 +2682,16 @@ int ms3d_spconv_layer_forward(const float *x, const float *W, const int *nbr_fwd
                               const int *pl_tile_start, const int *pl_entries, void *ev_start, void *ev_stop,
                               ms3d_stream_t stream)
 {
-    const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);  // wf_buf = [wf | wf streamed | wft | wft streamed]
-    float *wf = wf_buf, *wft = wf_buf + 2 * nwf;
-    int rc = W ? ms3d_spconv_prep_weights_pair(W, K, Cin, Cout, mirror_bwd, wf, wft, wf + nwf, wft + nwf, stream) : 0;  // W == NULL: wf_buf is current
+    const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);  // wf_buf = [wf | aux (2n) | wft | aux (2n)], 6n floats
+    float *wf = wf_buf, *wft = wf_buf + 3 * nwf;
+    const int aux_kind = ms3d_spconv_aux_kind(K, Cin, Cout);
+    int rc = W ? prep_weights_pair_impl(W, K, Cin, Cout, mirror_bwd, wf, wft, wf + nwf, wft + nwf, aux_kind, (hipStream_t)stream) : 0;  // W == NULL: wf_buf is current
     if (rc) return rc;
     // optional HIP events bracketing ONLY the convolution kernel, on the stream it is launched on (bench.py roofline)
     if (ev_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
-    rc = ms3d_spconv_forward(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
+    rc = spconv_forward_impl(x, wf, nbr_fwd, Vout, K, Cin, Cout, y, pre_scale, pre_shift, pre_relu, residual, nullptr,
                              nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial != nullptr, bias, pl_tile_start,
-                             pl_entries, wf + nwf, stream);
+                             pl_entries, wf + nwf, aux_kind, stream);
     if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return rc;
 }
@@ -2350,7 +2741,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                ms3d_stream_t wgrad_stream, int join, ms3d_stream_t stream)
 {
     const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
-    const float *wft = wf_buf + 2 * nwf, *wfts = wf_buf + 3 * nwf;
+    const float *wft = wf_buf + 3 * nwf, *wfts = wf_buf + 4 * nwf;
+    const int aux_kind = ms3d_spconv_aux_kind(K, Cin, Cout);
     const bool bn = scale != nullptr;
     int rc;
     // Backward-weight needs x and dy only, not the backward-data result: with a second stream (and its own slab
@@ -2382,9 +2774,9 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     if (ev_start && (need_dx || bn)) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, main));
     if (need_dx || bn) {
         if (!bn) {
-            rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+            rc = spconv_forward_impl(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts,
-                                     stream);
+                                     aux_kind, stream);
             if (rc) return rc;
             if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, main));
             ev_stop = nullptr;
@@ -2392,8 +2784,9 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
             const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, pl_bwd_tile_start && pl_bwd_entries);
             float *partial = ws;
-            rc = ms3d_spconv_forward(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
-                                     mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts, stream);
+            rc = spconv_forward_impl(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
+                                     mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts, aux_kind,
+                                     stream);
             if (rc) return rc;
             if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, main));
             ev_stop = nullptr;

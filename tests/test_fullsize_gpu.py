@@ -437,6 +437,58 @@ def test_unet_gradients_vs_fp64_on_a_full_scene(with_relu):
         assert e <= bar, (n_, e)
 
 
+@pytest.mark.parametrize("cin,cout,level", [(64, 64, 1), (96, 96, 2), (128, 128, 2), (64, 128, 2)])
+def test_bf16x3_wide_layers_are_float32_grade(be, cin, cout, level):
+    """Wide square layers run their forward / backward-data convolution on THREE-PIECE bf16 operands
+    (v_mfma_f32_16x16x32_bf16: x = x0 + x1 + x2 exactly, six products down to 2^-16; csrc/spconv.hip, write_bf3 /
+    spconv_fwd_bf3_kernel).  `dtype: "f32"` stays honest only if that is float32-grade: on the benchmark's level-1 / level-2
+    tables, against a float64 gather-matmul, the error of the bf16x3 path must stay within 3e-6 of the largest output AND
+    be no worse than 1.5x what the exact-f32 MFMA kernel loses on the same data (+2e-7) -- measured 1.7-2.0e-6 against
+    1.3-1.6e-6: a sum of ~1700 products rounds that much in float32 either way -- forward (fused BatchNorm + ReLU
+    prologue) and backward-data (fused BatchNorm-backward mask)."""
+    import bench
+    from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
+    dev = torch.device("cuda", 0)
+    b = bench.make_batch([0, 1, 2, 3], dev)
+    cm = CoordinateManager(b["voxel_xyz"].int().contiguous(), spatial_sort=True)
+    ts = 1
+    for _ in range(level):
+        cm.k2(ts); ts *= 2
+    nbr, V, K = cm.k3(ts), cm.size(ts), 27
+    kind = be.lib.ms3d_spconv_aux_kind(K, cin, cout)
+    assert kind == (2 if cin == cout else 1)          # rectangular layers keep the streamed f32 image
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(V, cin, device=dev, generator=g) * 2 + 0.5
+    W = torch.randn(K, cin, cout, device=dev, generator=g) / (cin * 12) ** 0.5
+    scale = torch.rand(cin, device=dev, generator=g) + 0.5
+    shift = torch.randn(cin, device=dev, generator=g) * 0.3
+    act = torch.relu(x.double() * scale.double() + shift.double())
+    want = _ref_conv(act, W.double(), nbr)
+    y, _, wf_buf = be.conv_layer_forward(x, W, nbr, V, K, cin, cout, True, (scale, shift), True, None, None, False)
+    wf = be.prep_weights(W, K, cin, cout)
+    y32 = be.conv_forward(x, wf, nbr, V, K, cin, cout, pre=(scale, shift), pre_relu=True)      # exact-f32 MFMA kernel
+    ref = want.abs().max()
+    e_split, e_f32 = ((y.double() - want).abs().max() / ref).item(), ((y32.double() - want).abs().max() / ref).item()
+    print(f"{cin}->{cout} rows={V}: forward vs fp64  bf16x3 {e_split:.2e}  f32 MFMA {e_f32:.2e}")
+    assert e_split <= 3e-6 and e_split <= 1.5 * e_f32 + 2e-7
+    if kind != 2:
+        assert torch.equal(y, y32)                    # same kernel on both routes
+        return
+    # backward-data: dx = conv^T(dy) masked by the fused BatchNorm + ReLU of the forward pass, then the BatchNorm chain
+    dy = torch.randn(V, cout, device=dev, generator=g)
+    mean, invstd = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
+    bn = dict(scale=scale, shift=shift, mean=mean, invstd=invstd, relu=True, training=False)
+    dx, dgb, dW = be.conv_layer_backward(x, dy, wf_buf, nbr, nbr, V, V, K, cin, cout, bn, True)
+    da = _ref_conv(dy.double(), W.double().flip(0).transpose(1, 2), nbr)
+    want_dx = da * (x.double() * scale.double() + shift.double() > 0) * scale.double()
+    e_dx = ((dx.double() - want_dx).abs().max() / want_dx.abs().max()).item()
+    print(f"{cin}->{cout}: backward-data vs fp64  bf16x3 {e_dx:.2e}")
+    assert e_dx <= 3e-6
+    want_dW = torch.stack([act[torch.where(nbr[k] >= 0, nbr[k], 0).long()].mul((nbr[k] >= 0)[:, None]).t() @ dy.double()
+                           for k in range(K)])
+    assert ((dW.double() - want_dW).abs().max() / want_dW.abs().max()).item() <= 1e-5
+
+
 def test_scatter_add_rows_vs_index_add(be):
     """ms3d_scatter_add_rows (backward of features[v2p_map], backbone.py:40; general_model.py:156; pointgroup.py:88):
     float atomics, compared with torch.index_add_ in fp64 at the benchmark's sizes, plus the degenerate index patterns"""

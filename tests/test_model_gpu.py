@@ -404,3 +404,35 @@ def test_ddp_two_ranks_on_one_gpu_stay_in_step(tmp_path):
     assert res[0][1] == res[1][1] == "minsu3d_amd.optim"      # the library's Adam is what stepped
     assert res[0][2] != res[1][2]                             # different scenes, different losses
     assert res[0][3] and res[1][3] and res[0][4]              # identical, finite parameters on both ranks
+
+
+def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
+    """MS3D_WGRAD_STREAM: the backward-weight kernels of every layer on a second stream beside the backward-data chain
+    (joined per layer = 1, or once at the end of the backward pass = 2) against the single-stream order: the same
+    kernels on the same data, so every gradient agrees to the float-atomic noise of the point <-> voxel scatter-adds
+    (a missing join would show as garbage), also when the step is repeated back to back"""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    be = HipBackend()
+    backend.set_backend(be)
+    u = tuple(t.cuda() for t in (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3])))
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((21, 22)).items()}
+    m = build_model(seed=5).cuda()
+    m.voxelization_rand = u
+    m.eval()                      # fixed BatchNorm statistics: no float-atomic noise between the runs
+    grads = {}
+    try:
+        for mode in (0, 1, 2, 2):
+            be._wgrad_mode = mode
+            m.zero_grad(set_to_none=True)
+            sum(m._loss(b, m(b)).values()).backward()
+            g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            if mode == 0:
+                grads = g
+            else:
+                assert g.keys() == grads.keys()
+                for n in g:
+                    scale = grads[n].abs().max().item()
+                    assert (g[n] - grads[n]).abs().max().item() <= 1e-4 * scale + 1e-12, (mode, n)
+    finally:
+        be._wgrad_mode = 0

@@ -342,7 +342,8 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
     from minsu3d_amd.backend import get_backend
     be = get_backend()
     g = torch.Generator().manual_seed(5)
-    shapes = [(27, 6, 16, True), (8, 48, 32, False), (1, 16, 16, False), (27, 80, 80, True), (8, 16, 33, False), (27, 16, 16, True)]
+    shapes = [(27, 6, 16, True), (8, 48, 32, False), (1, 16, 16, False), (27, 80, 80, True), (8, 16, 33, False), (27, 16, 16, True),
+              (27, 64, 96, True), (27, 96, 96, True)]
     layers, want = [], []
     for K, cin, cout, mirror in shapes:
         W = torch.randn(K, cin, cout, generator=g).cuda()
@@ -352,18 +353,38 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
     token = be.weight_token
     be.prep_weights_multi(layers)
     assert be.weight_token == token + 1
-    streamed = 0
-    for (W, buf, K, cin, cout, _), (wf, wft) in zip(layers, want):     # buffer = [wf | wf streamed | wft | wft streamed]
-        got = buf.view(2, 2, -1)
-        # the streamed images are written only for layers the weight-streaming kernel can serve (48 -> 32 here)
-        rows = slice(0, 2) if be.lib.ms3d_spconv_wants_stream_image(K, cin, cout) else slice(0, 1)
-        streamed += rows.stop - 1
-        assert torch.equal(got[0][rows], wf[rows]) and torch.equal(got[1][rows], wft[rows]), (K, cin, cout)
-        if rows.stop == 1:
-            assert torch.isnan(got[0][1]).all() and torch.isnan(got[1][1]).all()      # untouched
+    streamed = split = 0
+    for (W, buf, K, cin, cout, mirror), (wf, wft) in zip(layers, want):
+        # buffer = [image n | aux slot 2n | transposed image n | aux slot 2n]; aux = streamed f32 image (kind 1, the
+        # layers the weight-streaming kernel can serve: 48 -> 32 here), three-piece bf16 image (kind 2) or untouched
+        n = buf.numel() // 6
+        fwd, aux, bwd, aux_t = buf[:n], buf[n:3 * n], buf[3 * n:4 * n], buf[4 * n:]
+        kind = be.lib.ms3d_spconv_aux_kind(K, cin, cout)
+        assert torch.equal(fwd, wf[0]) and torch.equal(bwd, wft[0]), (K, cin, cout)
+        if kind == 1:
+            streamed += 1
+            assert torch.equal(aux[:n], wf[1]) and torch.equal(aux_t[:n], wft[1])
+            assert torch.isnan(aux[n:]).all() and torch.isnan(aux_t[n:]).all()
+        elif kind == 2:
+            split += 1
+            # Wb[k][c32][nb][piece][lane][e] = piece of W[k][32 c32 + 8 (lane >> 4) + e][16 nb + (lane & 15)]: the three
+            # bf16 pieces add up to the weight EXACTLY (24 = 3 x 8 mantissa bits)
+            for a, Wk, ci, co in ((aux, W, cin, cout), (aux_t, (W.flip(0) if mirror else W).transpose(1, 2), cout, cin)):
+                img = a[:n * 3 // 2].view(torch.bfloat16).view(K, ci // 32, co // 16, 3, 64, 8).float()
+                total = img.sum(3)                                              # [K, c32, nb, lane, e]
+                lane = torch.arange(64, device="cuda")
+                c = (32 * torch.arange(ci // 32, device="cuda")[:, None, None] + 8 * (lane >> 4)[None, :, None]
+                     + torch.arange(8, device="cuda")[None, None, :])          # [c32, lane, e]
+                j = 16 * torch.arange(co // 16, device="cuda")[:, None] + (lane & 15)[None, :]      # [nb, lane]
+                ref = Wk[:, c[:, None, :, :].expand(-1, co // 16, -1, -1), j[None, :, :, None].expand(ci // 32, -1, -1, 8)]
+                assert torch.equal(total, ref), (K, cin, cout)
+                assert torch.isnan(a[n * 3 // 2:]).all()
+        else:
+            assert torch.isnan(aux).all() and torch.isnan(aux_t).all()               # untouched
+    assert split >= 1
     assert streamed >= 1
     be.prep_weights_multi(layers[:2])          # a different set of tensors: the descriptor table is rebuilt
-    assert torch.equal(layers[1][1].view(2, 2, -1)[0][0], want[1][0][0])
+    assert torch.equal(layers[1][1][:layers[1][1].numel() // 6], want[1][0][0])
 
 
 @pytest.mark.parametrize("cin,cout,level", [(16, 16, 0), (32, 32, 1), (48, 48, 2)])

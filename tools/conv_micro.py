@@ -40,6 +40,18 @@ for _ in range(n):
     dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
 e1.record(); torch.cuda.synchronize()
 us_w = e0.elapsed_time(e1) / n * 1e3
+# the layer entry point (what the modules call): weight images incl. the aux image, fused BatchNorm / ReLU prologue
+scale = torch.rand(cin, device=dev) + 0.5; shift = torch.randn(cin, device=dev) * 0.2
+yl, _, wfb = be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, None, None, False)
+for _ in range(3):
+    be.conv_layer_forward(x, None, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, None, None, False, wf_ready=wfb)
+e0.record()
+for _ in range(n):
+    yl2, _, _ = be.conv_layer_forward(x, None, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, None, None, False, wf_ready=wfb)
+e1.record(); torch.cuda.synchronize()
+us_l = e0.elapsed_time(e1) / n * 1e3
+yref = be.conv_forward(x, wf, nbr, vout, K, cin, cout, pre=(scale, shift), pre_relu=True)
+err = ((yl2.double() - yref.double()).abs().max() / yref.double().abs().max()).item()
 alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
-print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | wgrad {us_w:.1f} us"
+print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | layer fwd {us_l:.1f} us (aux kind {be.lib.ms3d_spconv_aux_kind(K, cin, cout)}, vs f32 kernel {err:.1e}) | wgrad {us_w:.1f} us"
       f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
