@@ -266,6 +266,8 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
 /* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs
  * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
 int ms3d_spconv_wgrad_row_chunks(int Vout);
+/* floats of partial_ws a backward-weight call may use */
+size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout);
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
                                 int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                 float *partial_ws,

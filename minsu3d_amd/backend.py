@@ -810,8 +810,8 @@ class _HipEngine:
         x = self._dev(x); dout = self._dev(dout)
         dW = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
         ps, pb = (pre if pre is not None else (None, None))
-        chunks = self.lib.ms3d_spconv_wgrad_row_chunks(int(vout))
-        ws = self.ws.get("wgrad", chunks * K * cin * cout * 4, x.device)
+        self.lib.ms3d_spconv_wgrad_ws_floats.restype = C.c_size_t
+        ws = self.ws.get("wgrad", 4 * self.lib.ms3d_spconv_wgrad_ws_floats(int(vout), int(K), int(cin), int(cout)), x.device)
         ol = self.offsetlist(nbr, K, vout)
         _lib.check(self.lib.ms3d_spconv_backward_weight(
             _lib.ptr(x), _lib.ptr(dout), _lib.ptr(nbr), int(vout), int(K), int(cin), int(cout), _lib.ptr(dW),

@@ -1439,125 +1439,6 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     }
 }
 
-// Backward-weight on three-piece bf16 operands (wide layers; see the image comment at write_bf3 for the arithmetic).
-// The reduction dimension of dW[k] = sum_rows act(in[nbr_k(row)])^T dout[row] is the ROW: v_mfma_f32_16x16x32_bf16 takes
-// 32 rows per instruction (the f32 instruction 4), lane (channel cl, group q) holding rows r0 + 8q .. 8q + 7 of its
-// channel / column.  Both operands are split on the fly (exactly) into three bf16 pieces and the six products down to
-// 2^-16 are accumulated in f32: 6 instructions per 32 rows instead of 8 f32 instructions of twice the issue time.
-// Same grid, slabs and cross-wave reduction as spconv_wgrad_kernel.
-template <int KG, int NBT>
-__global__ __launch_bounds__(256) void spconv_wgrad_bf3_kernel(WgradArgs p)
-{
-    __shared__ float s_red[4 * NBT * 256];
-    const int l = lane_id(), q = l >> 4, cl = l & 15;
-    const int k0 = blockIdx.y * KG;
-    const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A elements
-    const bool c_ok = c < p.Cin;
-    const int c_safe = c_ok ? c : 0;
-    const float sc = (p.pre_scale && c_ok) ? p.pre_scale[c] : 1.f;
-    const float sh = (p.pre_scale && c_ok) ? p.pre_shift[c] : 0.f;
-    f32x4 acc[KG][NBT];
-#pragma unroll
-    for (int a = 0; a < KG; a++)
-#pragma unroll
-        for (int b = 0; b < NBT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int r_begin = blockIdx.x * p.rows_per_block;
-    const int r_end = min(p.Vout, r_begin + p.rows_per_block);
-    const int nw = blockDim.x >> 6;
-    for (int r0 = r_begin + wave_id() * 32; r0 < r_end; r0 += 32 * nw) {
-        const int rbase = r0 + 8 * q;           // this lane's 8 rows
-        // table entries of all KG offsets and the dout values of all column blocks: one round trip
-        int idx[KG][8];
-#pragma unroll
-        for (int kk = 0; kk < KG; kk++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int row = rbase + e;
-                const bool ok = row < r_end;
-                const int v = p.nbr[(size_t)min(k0 + kk, p.K - 1) * p.Vout + (ok ? row : r_begin)];
-                idx[kk][e] = v | ((k0 + kk < p.K && ok) ? 0 : -1);
-            }
-        bf16x8 bw[NBT][3];
-#pragma unroll
-        for (int nb = 0; nb < NBT; nb++) {
-            const int j = 16 * nb + cl;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int row = rbase + e;
-                const bool ok = row < r_end && j < p.Cout;
-                const float x = p.dout[(size_t)(row < r_end ? row : r_begin) * p.Cout + (j < p.Cout ? j : 0)];
-                v[e] = __int_as_float(__float_as_int(x) & (ok ? -1 : 0));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                __bf16 h0, h1, h2;
-                split3(v[e], h0, h1, h2);
-                bw[nb][0][e] = h0; bw[nb][1][e] = h1; bw[nb][2][e] = h2;
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < KG; kk++) {
-            int any = 0;
-#pragma unroll
-            for (int e = 0; e < 8; e++) any |= ~idx[kk][e];          // sign bit set <=> some entry >= 0
-            if (__ballot(any < 0) == 0ull) continue;                  // no row of the 32 has this neighbour
-            float a[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) a[e] = p.in[(size_t)max(idx[kk][e], 0) * p.Cin + c_safe];
-            bf16x8 a0, a1, a2;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float v = a[e];
-                if (p.pre_scale) {
-                    v = fmaf(v, sc, sh);
-                    if (p.pre_relu) v = fmaxf(v, 0.f);
-                }
-                v = __int_as_float(__float_as_int(v) & ~(idx[kk][e] >> 31) & (c_ok ? -1 : 0));
-                __bf16 h0, h1, h2;
-                split3(v, h0, h1, h2);
-                a0[e] = h0; a1[e] = h1; a2[e] = h2;
-            }
-#pragma unroll
-            for (int nb = 0; nb < NBT; nb++) {
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bw[nb][0], acc[kk][nb], 0, 0, 0);
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][2], acc[kk][nb], 0, 0, 0);
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw[nb][1], acc[kk][nb], 0, 0, 0);
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw[nb][0], acc[kk][nb], 0, 0, 0);
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][1], acc[kk][nb], 0, 0, 0);
-                acc[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[nb][0], acc[kk][nb], 0, 0, 0);
-            }
-        }
-    }
-    float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
-#pragma unroll
-    for (int kk = 0; kk < KG; kk++) {
-        const int k = k0 + kk;
-        __syncthreads();
-#pragma unroll
-        for (int nb = 0; nb < NBT; nb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) s_red[(wave_id() * NBT + nb) * 256 + r * 64 + l] = acc[kk][nb][r];
-        __syncthreads();
-        for (int e = threadIdx.x; e < NBT * 256; e += blockDim.x) {
-            float v = 0.f;
-            for (int w = 0; w < nw; w++) v += s_red[w * NBT * 256 + e];
-            const int nb = e >> 8, r = (e >> 6) & 3, ln = e & 63;
-            const int ci = blockIdx.z * 16 + 4 * (ln >> 4) + r, j = 16 * nb + (ln & 15);
-            if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
-        }
-    }
-}
-
-template <int KG, int NBT>
-int launch_wgrad_bf3(const WgradArgs &p, int nblk_rows, hipStream_t stream)
-{
-    dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
-    spconv_wgrad_bf3_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
-    MS3D_LAUNCH_CHECK();
-    return 0;
-}
-
 // dW[e] = sum over row chunks of partial[b][e].  Block = 16 elements x 16 slab lanes: lane j sums slabs j, j+16, ...
 // and the 16 lane sums are combined in lane order -> fixed order, deterministic; 16x the threads of one-thread-per-
 // element (the slab walk is latency-bound: 251 slabs took 21 us).
@@ -2481,6 +2362,11 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     return MS3D_E_UNSUPPORTED;
 }
 
+size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout)
+{
+    return (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout + 64;
+}
+
 int ms3d_spconv_wgrad_row_chunks(int Vout)
 {
     // ~1024+ waves in flight at full resolution, at most 256 partial slabs (the slab reduction reads chunks * |dW|)
@@ -2528,13 +2414,6 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     }
     const int nb = p.NBtot;
     if (nb > 14) return MS3D_E_UNSUPPORTED;
-    static const bool bf3_on = [] { const char *e = getenv("MS3D_BF16X3"); return !e || atoi(e) != 0; }();
-    static const bool bf3_wgrad = [] { const char *e = getenv("MS3D_BF16X3_WGRAD"); return e && atoi(e) != 0; }();   // experiment: measured slower
-    const bool bf3 = bf3_wgrad && !use_list && bf3_on && K > 1 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin % 16 == 0 && Cout % 16 == 0;
-    if (bf3) {   // a workgroup's four waves take 32 rows each per trip
-        p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 128) * 128;
-        nblk = ms3d_divup(Vout, p.rows_per_block);
-    }
     int rc;
     if (use_list) {
         // two input chunks per workgroup when Cin allows (entries and dout rows fetched once for both)
@@ -2543,16 +2422,6 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
            : nb == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
            : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
-        if (rc) return rc;
-        launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
-        MS3D_LAUNCH_CHECK();
-        return 0;
-    }
-    if (bf3) {
-        // wide layers: three-piece bf16 operands (f32-grade), 2.7x less matrix-pipe time
-        rc = nb == 3 ? launch_wgrad_bf3<4, 3>(p, nblk, stream) : nb == 4 ? launch_wgrad_bf3<4, 4>(p, nblk, stream)
-           : nb == 5 ? launch_wgrad_bf3<4, 5>(p, nblk, stream) : nb == 6 ? launch_wgrad_bf3<3, 6>(p, nblk, stream)
-           : nb == 7 ? launch_wgrad_bf3<2, 7>(p, nblk, stream) : launch_wgrad_bf3<2, 8>(p, nblk, stream);
         if (rc) return rc;
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
         MS3D_LAUNCH_CHECK();
@@ -2670,7 +2539,7 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
     };
     const size_t pf = blocks(Vout, K, Cin, Cout) * 2 * Cout;
     const size_t pb = blocks(Vin, K, Cout, Cin) * 2 * Cin;
-    const size_t wg = (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout;
+    const size_t wg = ms3d_spconv_wgrad_ws_floats(Vout, K, Cin, Cout);
     return wf + (pf > pb ? pf : pb) + wg + 2 * (size_t)Cin + 64;
 }
 
