@@ -665,6 +665,150 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
     }
 }
 
+// ---- small levels on the three-piece bf16 image: one block per (tile, column slice), its waves split the K offsets,
+// B operands (16 bytes per lane and piece) straight from the L2-resident image, no LDS staging -- the bf16x3 counterpart
+// of spconv_fwd_small_kernel.  The operands of the NEXT (offset, column group) are requested before the current group's
+// MFMAs (two register sets, unconditional loads); an offset no row of the tile has skips its MFMAs only.
+template <int NBT>
+__global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    constexpr int NG = (NBT + 3) / 4;              // column groups of at most 4 blocks (12 operand loads in flight)
+    constexpr int GB = NBT / NG, GR = NBT % NG;     // the first GR groups hold GB + 1 blocks
+    const int l = lane_id(), g8 = l >> 4;
+    const int waves = blockDim.x >> 6;  // = ceil(K / OG)
+    const int nb0 = blockIdx.y * NBT;
+    const int NC32 = p.Cin >> 5;
+    float *s_acc = lds;                                        // [(waves-1)][NBT][4][64]
+    float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // [2*Cout] when bn_x / out_stats
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) {
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    }
+    const int tile = blockIdx.x;
+    const int row0 = tile * 16, my_row = row0 + (l & 15);
+    const bool row_ok = my_row < p.Vout;
+    const int safe_row = row_ok ? my_row : 0;
+    f32x4 acc[NBT];
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
+    const int k_lo = wave_id() * OG, k_hi = min(p.K, k_lo + OG);
+    for (int k0 = k_lo; k0 < k_hi; k0 += OGB) {
+        int idx[OGB];
+#pragma unroll
+        for (int u = 0; u < OGB; u++) {
+            const int k = min(k0 + u, k_hi - 1);
+            const int v = p.nbr[(size_t)k * p.Vout + safe_row];
+            idx[u] = v | ((row_ok && k0 + u < k_hi) ? 0 : -1);
+        }
+        bool any[OGB];
+#pragma unroll
+        for (int u = 0; u < OGB; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
+        for (int c32 = 0; c32 < NC32; c32++) {
+            const int c0 = 32 * c32 + 8 * g8;
+            f32x4 lo[OGB], hi[OGB];
+#pragma unroll
+            for (int u = 0; u < OGB; u++) {
+                const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
+                lo[u] = *reinterpret_cast<const f32x4 *>(row);
+                hi[u] = *reinterpret_cast<const f32x4 *>(row + 4);
+            }
+            const float *ps = p.pre_scale ? p.pre_scale : p.in, *pb = p.pre_scale ? p.pre_shift : p.in;
+            const f32x4 s0 = *reinterpret_cast<const f32x4 *>(ps + c0), s1 = *reinterpret_cast<const f32x4 *>(ps + c0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(pb + c0), b1 = *reinterpret_cast<const f32x4 *>(pb + c0 + 4);
+            // B operands of (offset u, column group cg): [GB + 1][3 pieces] x 16 B, two sets
+            uint4 wb[2][(GB + 1) * 3];
+            auto load_b = [&](int u, int cg, uint4 (&dst)[(GB + 1) * 3]) {
+                const int kk = min(min(k0 + u, k_hi - 1), p.K - 1);
+                const int first = cg * GB + (cg < GR ? cg : GR);
+                const uint4 *w = img + ((size_t)(kk * NC32 + c32) * p.NBtot + nb0 + first) * 3 * 64 + l;
+#pragma unroll
+                for (int i = 0; i < (GB + 1) * 3; i++) dst[i] = w[min(i, (NBT - first) * 3 - 1) * 64];
+            };
+            load_b(0, 0, wb[0]);
+#pragma unroll
+            for (int u = 0; u < OGB; u++) {
+                bf16x8 a0, a1, a2;
+                if (any[u]) {
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { v[t] = lo[u][t]; v[4 + t] = hi[u][t]; }
+                    if (p.pre_scale) {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float x0 = fmaf(v[t], s0[t], b0[t]), x1 = fmaf(v[4 + t], s1[t], b1[t]);
+                            v[t] = p.pre_relu ? fmaxf(x0, 0.f) : x0;
+                            v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
+                        }
+                    }
+                    const int keep = ~(idx[u] >> 31);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        __bf16 h0, h1, h2;
+                        split3(__int_as_float(__float_as_int(v[e]) & keep), h0, h1, h2);
+                        a0[e] = h0; a1[e] = h1; a2[e] = h2;
+                    }
+                }
+#pragma unroll
+                for (int cg = 0; cg < NG; cg++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int stage = u * NG + cg;                       // compile-time after unrolling
+                    // next stage's operands first
+                    if (cg + 1 < NG) load_b(u, cg + 1, wb[(stage + 1) & 1]);
+                    else if (u + 1 < OGB) load_b(u + 1, 0, wb[(stage + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (any[u]) {
+                        const int first = cg * GB + (cg < GR ? cg : GR), count = GB + (cg < GR ? 1 : 0);
+#pragma unroll
+                        for (int i = 0; i < GB + 1; i++) {
+                            if (i >= count) continue;
+                            const uint4 &r0 = wb[stage & 1][i * 3 + 0], &r1 = wb[stage & 1][i * 3 + 1], &r2 = wb[stage & 1][i * 3 + 2];
+                            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&r0), w1 = *reinterpret_cast<const bf16x8 *>(&r1),
+                                         w2 = *reinterpret_cast<const bf16x8 *>(&r2);
+                            f32x4 &d = acc[first + i];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w0, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w2, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w1, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, d, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (wave_id() > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_acc[((size_t)(wave_id() - 1) * NBT + nb) * 256 + r * 64 + l] = acc[nb][r];
+    }
+    __syncthreads();
+    if (wave_id() == 0) {
+        for (int w = 1; w < waves; w++)
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[nb][r] += s_acc[((size_t)(w - 1) * NBT + nb) * 256 + r * 64 + l];
+        store_tile<NBT>(p, row0, nb0, acc, s_part);
+    }
+    if (with_partial) {
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT>
+int launch_fwd_small_bf3(const ConvArgs &p, dim3 grid, int threads, size_t lds, hipStream_t stream)
+{
+    spconv_fwd_small_bf3_kernel<NBT><<<grid, threads, lds, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NBT>
 int launch_fwd_small(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
 {
@@ -2319,6 +2463,18 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
         if (g.nbt == 1 && p.NCH == 3) return launch_fwd_pairlist<1, 3>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 4) return launch_fwd_pairlist<1, 4>(p, grid, g.threads, g.lds, stream);
         return MS3D_E_UNSUPPORTED;
+    }
+    if (g.small && aux_kind == 2 && wf_stream && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2) {
+        p.wfb = wf_stream;
+        switch (g.nbt) {
+            case 2: return launch_fwd_small_bf3<2>(p, grid, g.threads, g.lds, stream);
+            case 3: return launch_fwd_small_bf3<3>(p, grid, g.threads, g.lds, stream);
+            case 4: return launch_fwd_small_bf3<4>(p, grid, g.threads, g.lds, stream);
+            case 5: return launch_fwd_small_bf3<5>(p, grid, g.threads, g.lds, stream);
+            case 6: return launch_fwd_small_bf3<6>(p, grid, g.threads, g.lds, stream);
+            case 7: return launch_fwd_small_bf3<7>(p, grid, g.threads, g.lds, stream);
+            case 8: return launch_fwd_small_bf3<8>(p, grid, g.threads, g.lds, stream);
+        }
     }
     if (g.small) {
         switch (g.nbt) {
