@@ -99,7 +99,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __host__ __device__ inline bool bf3_dims_ok(int K, int Cin, int Cout)
 {
-    return K > 1 && Cin % 32 == 0 && Cout % 32 == 0 && Cin >= 64 && Cout >= 64 && Cin <= 256 && Cout <= 256;
+    // input channels are padded to a multiple of 32 with zero weights (48 -> 64, 80 -> 96, 112 -> 128: the image still
+    // fits the aux slot of 2n floats: 1.5 n * 64/48 = 2 n)
+    return K > 1 && Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 48 && Cout >= 48 && Cin <= 256 && Cout <= 256;
 }
 
 __device__ __forceinline__ void split3(float v, __bf16 &h0, __bf16 &h1, __bf16 &h2)
@@ -114,7 +116,7 @@ __device__ __forceinline__ void split3(float v, __bf16 &h0, __bf16 &h1, __bf16 &
 __device__ __forceinline__ void write_bf3(float *aux, int k, int c, int j, int Cin_e, int NB, float v)
 {
     __bf16 *img = reinterpret_cast<__bf16 *>(aux);
-    const int NC32 = Cin_e >> 5, c32 = c >> 5, g = (c >> 3) & 3, e = c & 7, nb = j >> 4, jl = j & 15;
+    const int NC32 = (Cin_e + 31) >> 5, c32 = c >> 5, g = (c >> 3) & 3, e = c & 7, nb = j >> 4, jl = j & 15;
     const size_t base = ((((size_t)k * NC32 + c32) * NB + nb) * 3) * 64 + (jl + 16 * g);
     __bf16 h0, h1, h2;
     split3(v, h0, h1, h2);
@@ -143,7 +145,10 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
             const float v = (c < Cout_e && j < Cin_e) ? W[((size_t)ks * Cin_e + j) * Cout_e + c] : 0.f;
             wf2[o] = v;
             if (wfs2 && aux_kind == 1) wfs2[stream_slot(o, NBtot2)] = v;
-            if (wfs2 && aux_kind == 2 && c < Cout_e && j < Cin_e) write_bf3(wfs2, k, c, j, Cout_e, NBtot2, v);
+            if (wfs2 && aux_kind == 2 && c < Cout_e && j < Cin_e) {
+                write_bf3(wfs2, k, c, j, Cout_e, NBtot2, v);
+                if ((Cout_e & 16) && c >= Cout_e - 16) write_bf3(wfs2, k, c + 16, j, Cout_e, NBtot2, 0.f);   // zero pad
+            }
         }
     }
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -161,7 +166,10 @@ __global__ void prep_weights_kernel(const float *__restrict__ W, float *__restri
                           : W[((size_t)ks * Cin_e + c) * Cout_e + j];
         wf[o] = v;
         if (wfs && aux_kind == 1) wfs[stream_slot(o, NBtot)] = v;
-        if (wfs && aux_kind == 2 && c < Cin_e && j < Cout_e) write_bf3(wfs, k, c, j, Cin_e, NBtot, v);
+        if (wfs && aux_kind == 2 && c < Cin_e && j < Cout_e) {
+            write_bf3(wfs, k, c, j, Cin_e, NBtot, v);
+            if ((Cin_e & 16) && c >= Cin_e - 16) write_bf3(wfs, k, c + 16, j, Cin_e, NBtot, 0.f);              // zero pad
+        }
     }
 }
 
@@ -198,7 +206,10 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const float v = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
         d.wf[o] = v;
         if (d.stream == 1) d.wf[total + stream_slot(o, NB)] = v;
-        if (d.stream == 2 && c < d.Cin && j < d.Cout) write_bf3(d.wf + total, k, c, j, d.Cin, NB, v);
+        if (d.stream == 2 && c < d.Cin && j < d.Cout) {
+            write_bf3(d.wf + total, k, c, j, d.Cin, NB, v);
+            if ((d.Cin & 16) && c >= d.Cin - 16) write_bf3(d.wf + total, k, c + 16, j, d.Cin, NB, 0.f);           // zero pad
+        }
     }
     {
         long r = o >> 6;
@@ -210,7 +221,10 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const float v = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
         d.wft[o] = v;
         if (d.stream == 1) d.wft[total + stream_slot(o, NCH)] = v;
-        if (d.stream == 2 && c < d.Cout && j < d.Cin) write_bf3(d.wft + total, k, c, j, d.Cout, NCH, v);
+        if (d.stream == 2 && c < d.Cout && j < d.Cin) {
+            write_bf3(d.wft + total, k, c, j, d.Cout, NCH, v);
+            if ((d.Cout & 16) && c >= d.Cout - 16) write_bf3(d.wft + total, k, c + 16, j, d.Cout, NCH, 0.f);       // zero pad
+        }
     }
 }
 
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     const int l = lane_id(), g8 = l >> 4;
     const int waves = blockDim.x >> 6;
     const int nb0 = blockIdx.y * NBT;
-    const int NC32 = p.Cin >> 5;
+    const int NC32 = (p.Cin + 31) >> 5;
     uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][c32][nb][piece][lane] x 16 B
     float *s_part = lds + (size_t)p.G * NC32 * NBT * 3 * 64 * 4;           // [2*Cout] when statistics are asked for
     const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
@@ -518,7 +532,9 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
 #pragma unroll
             for (int u = 0; u < OGB; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
             for (int c32 = 0; c32 < NC32; c32++) {
-                const int c0 = 32 * c32 + 8 * g8;
+                const int cr = 32 * c32 + 8 * g8;
+                const int c_keep = cr < p.Cin ? -1 : 0;     // Cin = 48, 80, 112: the upper half of the last chunk is padding
+                const int c0 = cr < p.Cin ? cr : p.Cin - 8;
                 f32x4 lo[OGB], hi[OGB];
 #pragma unroll
                 for (int u = 0; u < OGB; u++) {     // unconditional, clamped (a branch around a gather drains the counter)
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
                             v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
                         }
                     }
-                    const int keep = ~(idx[u] >> 31);   // absent neighbour (idx < 0) contributes nothing
+                    const int keep = ~(idx[u] >> 31) & c_keep;   // absent neighbour (idx < 0) / padded channels contribute nothing
                     bf16x8 a0, a1, a2;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
@@ -678,7 +694,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
     const int l = lane_id(), g8 = l >> 4;
     const int waves = blockDim.x >> 6;  // = ceil(K / OG)
     const int nb0 = blockIdx.y * NBT;
-    const int NC32 = p.Cin >> 5;
+    const int NC32 = (p.Cin + 31) >> 5;
     float *s_acc = lds;                                        // [(waves-1)][NBT][4][64]
     float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // [2*Cout] when bn_x / out_stats
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
@@ -706,7 +722,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
 #pragma unroll
         for (int u = 0; u < OGB; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
         for (int c32 = 0; c32 < NC32; c32++) {
-            const int c0 = 32 * c32 + 8 * g8;
+            const int cr = 32 * c32 + 8 * g8;
+            const int c_keep = cr < p.Cin ? -1 : 0;
+            const int c0 = cr < p.Cin ? cr : p.Cin - 8;
             f32x4 lo[OGB], hi[OGB];
 #pragma unroll
             for (int u = 0; u < OGB; u++) {
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
                             v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
                         }
                     }
-                    const int keep = ~(idx[u] >> 31);
+                    const int keep = ~(idx[u] >> 31) & c_keep;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         __bf16 h0, h1, h2;
@@ -2492,7 +2510,7 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     if (aux_kind == 2 && wf_stream && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2) {
         // same grid as the f32 table walk (the statistics partials are sized for it); only the staged group shrinks:
         // three bf16 pieces are 6 bytes per weight
-        const size_t per_offset = (size_t)(Cin / 32) * g.nbt * 3 * 1024;
+        const size_t per_offset = (size_t)((Cin + 31) / 32) * g.nbt * 3 * 1024;
         const size_t extra = (bn_x != nullptr || p.out_stats) ? 2 * (size_t)Cout * sizeof(float) : 0;
         int G = (int)((LDS_BUDGET - extra) / per_offset);
         if (G > K) G = K;

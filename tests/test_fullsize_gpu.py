@@ -437,7 +437,8 @@ def test_unet_gradients_vs_fp64_on_a_full_scene(with_relu):
         assert e <= bar, (n_, e)
 
 
-@pytest.mark.parametrize("cin,cout,level", [(64, 64, 1), (96, 96, 2), (128, 128, 2), (64, 128, 2)])
+@pytest.mark.parametrize("cin,cout,level", [(64, 64, 1), (96, 96, 2), (128, 128, 2), (64, 128, 2), (48, 48, 2), (96, 48, 2),
+                                            (80, 80, 3), (112, 112, 3)])
 def test_bf16x3_wide_layers_are_float32_grade(be, cin, cout, level):
     """Wide square layers run their forward / backward-data convolution on THREE-PIECE bf16 operands
     (v_mfma_f32_16x16x32_bf16: x = x0 + x1 + x2 exactly, six products down to 2^-16; csrc/spconv.hip, write_bf3 /

@@ -370,15 +370,18 @@ def test_weight_images_of_many_layers_in_one_launch_bit_exact():
             # Wb[k][c32][nb][piece][lane][e] = piece of W[k][32 c32 + 8 (lane >> 4) + e][16 nb + (lane & 15)]: the three
             # bf16 pieces add up to the weight EXACTLY (24 = 3 x 8 mantissa bits)
             for a, Wk, ci, co in ((aux, W, cin, cout), (aux_t, (W.flip(0) if mirror else W).transpose(1, 2), cout, cin)):
-                img = a[:n * 3 // 2].view(torch.bfloat16).view(K, ci // 32, co // 16, 3, 64, 8).float()
+                nc32 = (ci + 31) // 32                 # input channels are padded to a multiple of 32 with zero weights
+                used = K * nc32 * (co // 16) * 3 * 64 * 8 // 2      # floats the image occupies
+                img = a[:used].view(torch.bfloat16).view(K, nc32, co // 16, 3, 64, 8).float()
                 total = img.sum(3)                                              # [K, c32, nb, lane, e]
                 lane = torch.arange(64, device="cuda")
-                c = (32 * torch.arange(ci // 32, device="cuda")[:, None, None] + 8 * (lane >> 4)[None, :, None]
+                c = (32 * torch.arange(nc32, device="cuda")[:, None, None] + 8 * (lane >> 4)[None, :, None]
                      + torch.arange(8, device="cuda")[None, None, :])          # [c32, lane, e]
                 j = 16 * torch.arange(co // 16, device="cuda")[:, None] + (lane & 15)[None, :]      # [nb, lane]
-                ref = Wk[:, c[:, None, :, :].expand(-1, co // 16, -1, -1), j[None, :, :, None].expand(ci // 32, -1, -1, 8)]
+                Wp = torch.cat([Wk, Wk.new_zeros(K, 32 * nc32 - ci, co)], 1)
+                ref = Wp[:, c[:, None, :, :].expand(-1, co // 16, -1, -1), j[None, :, :, None].expand(nc32, -1, -1, 8)]
                 assert torch.equal(total, ref), (K, cin, cout)
-                assert torch.isnan(a[n * 3 // 2:]).all()
+                assert used <= 2 * n and torch.isnan(a[used:]).all()
         else:
             assert torch.isnan(aux).all() and torch.isnan(aux_t).all()               # untouched
     assert split >= 1
