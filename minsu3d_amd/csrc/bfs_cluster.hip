@@ -356,6 +356,7 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                         }
                         __syncthreads();
                         int j = -1, lo = 0, slot = 0;
+                        int2 hdr = make_int2(0, 0);
                         bool ok = false;
                         if (tid < E) {
                             int hi = F;  // largest p with pref[p] <= e
@@ -364,7 +365,13 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                                 if (s_pref[mid] <= tid) lo = mid; else hi = mid;
                             }
                             j = ball_idx[s_fst[fbuf][lo] + (tid - s_pref[lo])];
-                            ok = (thr.mode != 0 || (int)sem[j] == lab) && visited[j] == 0;
+                            // one round trip for everything that hangs on j: label, visited flag AND the target's own list
+                            // header (needed only if it wins -- fetched with the test instead of after it: a level is
+                            // two dependent round trips, edge targets -> target records, instead of three)
+                            const int lj = thr.mode == 0 ? (int)sem[j] : lab;
+                            const int vj = visited[j];
+                            hdr = *reinterpret_cast<const int2 *>(start_len + 2 * (size_t)j);
+                            ok = lj == lab && vj == 0;
                             if (ok) {
                                 // all edges of the level are in this workgroup: the smallest parent position per target
                                 // is settled in LDS (open addressing, <= 512 keys in 1024 slots), no memory-side atomics
@@ -386,8 +393,8 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                                 scratch_seed[new_tail + rank] = seed;
                                 visited[j] = 1;
                                 if (rank < NT) {   // (tot <= E <= NT)
-                                    s_fst[fbuf ^ 1][rank] = start_len[j * 2];
-                                    s_fln[fbuf ^ 1][rank] = start_len[j * 2 + 1];
+                                    s_fst[fbuf ^ 1][rank] = hdr.x;
+                                    s_fln[fbuf ^ 1][rank] = hdr.y;
                                 }
                             }
                         }
