@@ -170,9 +170,14 @@ def _conv_variant(kind, K, cin, cout, rows, lib):
     listed = bool(lib.ms3d_kmap_pairlist_wanted(int(K), int(rows)))
     if kind == "spconv_wgrad":
         return "offset-list" if listed and cin <= 64 and cout <= 64 else "table-walk"
+    split = "bf16x3 " if int(lib.ms3d_spconv_aux_kind(int(K), int(cin), int(cout))) == 2 else ""
     if -(-rows // 16) <= 1100 and -(-cin // 16) * -(-cout // 16) >= 4:
-        return "small"
-    return "pair-list" if listed and max(cin, cout) <= 32 else "table-walk"
+        return split + "small"
+    if listed and max(cin, cout) <= 32:
+        return "pair-list"
+    if listed and not split and int(lib.ms3d_spconv_wants_stream_image(int(K), int(cin), int(cout))):
+        return "weight-stream"
+    return split + "table-walk"
 
 
 def kernel_source_digest():
@@ -201,6 +206,8 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
             "kernel_ms_per_step": round(tot["ms"] / n_sampled, 3),
             "algorithmic_bytes_per_step": int(tot["bytes"] / n_sampled),
             "flops_per_step": int(tot["flops"] / n_sampled),
+            # useful f32-equivalent flops against the f32 MFMA peak (layers on three-piece bf16 operands issue 6 bf16
+            # instructions per 32 channels instead of 8 f32 ones: the figure is NOT matrix-pipe occupancy for them)
             "mfma_f32_frac": round(tot["flops"] / (tot["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
             "steps_sampled": n_sampled}
     # HBM bytes of the same kernels from the PMC passes committed with this code (separate rocprofv3 --pmc FETCH_SIZE /

@@ -32,6 +32,7 @@
 // (nCluster, sumNPoint) read the caller needs to size its tensors.
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 #include "scan.h"
 #include "../../include/minsu3d_hip.h"
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(256) void glob_mark_kernel(
         if (gid == 0) {
             counters[8] = 0;
             counters[6 + ((level + 1) & 1)] = 0;
+            if (nF > 0) counters[14] = level + 1;   // depth so far: the host sizes the next call's speculative launch by it
         }
     }
     const int waves = blockDim.x >> 6, l = lane_id();
@@ -1244,6 +1246,8 @@ int ms3d_bfs_run_internal(int mode, int thr_i, float thr_f, int capped_hint, con
                           void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 namespace {
+std::atomic<int> g_dense_depth_hint{10};   // levels the last dense-graph expansion needed
+
 int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, long n_edges, const int *start_len, int N,
             int *cluster_idxs,
             int *cluster_offsets, int *counts, void *workspace, size_t workspace_bytes, hipStream_t stream)
@@ -1371,11 +1375,14 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     int host[16];
     for (;;) {
         if (dense) {
-            // 16 levels are launched speculatively (a shifted-coordinate blob is exhausted after ~10) and the frontier
-            // counter is read together with the final counts; a deeper component simply gets 16 more levels -- the
+            // the levels are launched speculatively (a shifted-coordinate blob is exhausted after ~10) and the frontier
+            // counter is read together with the final counts; a deeper component simply gets 8 more levels -- the
             // assembly below is idempotent
             if (level > 60000) return MS3D_E_UNSUPPORTED;  // 16-bit level field of the node word
-            int rc2 = run_levels(16);
+            // how many levels to launch blind: what the last dense graph needed + 2 (an exhausted level still costs three
+            // ~5 us launches; 16 fixed levels spent ~0.2 ms per PointGroup step on empty ones)
+            const int spec = level == 0 ? min(24, max(6, g_dense_depth_hint.load() + 2)) : 8;
+            int rc2 = run_levels(spec);
             if (rc2) return rc2;
             DBG("after levels");
             glob_finish_kernel<<<wl_grid, 256, 0, stream>>>(w.worklist, w.counters, w.comp_size, w.comp_base, w.cl_size,
@@ -1404,7 +1411,10 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         MS3D_CHECK(hipStreamSynchronize(stream));
         if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d | %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8], host[9], level);
         if (dense) {
-            if (host[6 + (level & 1)] == 0) break;  // frontier empty: every component was exhausted
+            if (host[6 + (level & 1)] == 0) {       // frontier empty: every component was exhausted
+                g_dense_depth_hint.store(host[14]);
+                break;
+            }
             continue;
         }
         if (directed) {
