@@ -169,7 +169,10 @@ def _conv_variant(kind, K, cin, cout, rows, lib):
     """the kernel a convolution launch is served by (mirrors fwd_geometry / the wgrad dispatch in csrc/spconv.hip)"""
     listed = bool(lib.ms3d_kmap_pairlist_wanted(int(K), int(rows)))
     if kind == "spconv_wgrad":
-        return "offset-list" if listed and cin <= 64 and cout <= 64 else "table-walk"
+        ol = listed and cin <= 64 and cout <= 64
+        if lib.ms3d_spconv_wgrad_is_bf16x3(int(rows), int(K), int(cin), int(cout), int(ol)):
+            return "bf16x3 table-walk"
+        return "offset-list" if ol else "table-walk"
     split = "bf16x3 " if int(lib.ms3d_spconv_aux_kind(int(K), int(cin), int(cout))) == 2 else ""
     if -(-rows // 16) <= 1100 and -(-cin // 16) * -(-cout // 16) >= 4:
         return split + "small"

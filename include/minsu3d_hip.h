@@ -266,8 +266,11 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
 /* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs
  * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
 int ms3d_spconv_wgrad_row_chunks(int Vout);
-/* floats of partial_ws a backward-weight call may use */
+/* floats of partial_ws a backward-weight call may use (slabs; wide K = 27 layers add the three-piece bf16 images of both
+ * operands).  K = 27 is the submanifold case: `in` and `dout` have the same Vout rows. */
 size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout);
+/* 1 when a backward-weight call of this shape runs on three-piece bf16 operands (offset_list: an offset list is passed) */
+int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_list);
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin,
                                 int Cout, float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                 float *partial_ws,

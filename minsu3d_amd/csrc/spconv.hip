@@ -1601,6 +1601,225 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     }
 }
 
+// ---- backward-weight on three-piece bf16 operands (wide submanifold layers) --------------------------------------
+// The reduction dimension of dW[k] = sum_rows act(in[nbr_k(row)])^T dout[row] is the ROW: v_mfma_f32_16x16x32_bf16 takes 32
+// rows per instruction (the f32 instruction 4) and wants, per lane, EIGHT consecutive rows of its channel -- a column of
+// the row-major tensors.  Two elementwise passes per layer prepare both operands (exact three-way split, see write_bf3):
+//   dout -> its MFMA operands ready made (it is not gathered): img[((t*NB + nb)*3 + piece)*64 + lane][e] =
+//           piece of dout[32 t + 8 (lane >> 4) + e][16 nb + (lane & 15)]                  (split_rows_bf3)
+//   x    -> the ACTIVATED input act(x) = relu(x * scale + shift) as pieces, row-major: xs[(row*3 + piece)*C + c]
+//           (act_split_bf3; one launch does both: wgrad_bf3_operands_kernel)
+// A workgroup owns (row chunk, KG offsets, one 16-channel input chunk) and walks its rows 32 at a time.  Its waves SPLIT THE
+// OUTPUT COLUMNS (NBW blocks of 16 each) and share the gathered input: per trip the whole workgroup gathers the KG tiles of
+// 32 rows x 16 channels x 3 pieces (one 16-byte word per thread and entry, no word fetched twice), parks them ROW-major in
+// LDS, and every wave reads its MFMA operand back with the transposing LDS read: ds_read_b64_tr_b16 hands lane i of a
+// 16-lane group the element (i & 3) of the 8-byte chunk that lane 4r + (i >> 2) of the group addressed, r = 0..3 -- with
+// lane s addressing row base + (s >> 2), channels 4 (s & 3) .. +3, lane i receives rows base .. base + 3 of channel i
+// (tools/probe/tr_probe.hip prints the mapping).  A wave's dout operands (its own columns only) stay in registers for the
+// trip; the next trip's gathers, indices and dout operands are in flight during this trip's MFMAs.  Six earlier builds
+// (every wave gathering and transposing for itself; dout operands re-read from LDS per offset) were slower than the f32
+// kernel on operand traffic alone (profiles/r03_fwd_experiments.txt section 6).  No cross-wave reduction: every
+// accumulator belongs to one (offset, column block).  rows_per_block is a multiple of 32.
+__device__ __forceinline__ void split_rows_bf3(long blk, const float *__restrict__ x, long V, int C, int NB, long ntile,
+                                               bf16x8 *__restrict__ img)
+{
+    const long o = blk * 256 + threadIdx.x;          // (t, nb, lane)
+    if (o >= ntile * NB * 64) return;
+    const int lane = (int)(o & 63);
+    const long tn = o >> 6;
+    const int nb = (int)(tn % NB);
+    const long t = tn / NB;
+    const int j = 16 * nb + (lane & 15);
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const long row = 32 * t + 8 * (lane >> 4) + e;
+        const float v = (row < V && j < C) ? x[row * C + j] : 0.f;
+        __bf16 h0, h1, h2;
+        split3(v, h0, h1, h2);
+        p0[e] = h0; p1[e] = h1; p2[e] = h2;
+    }
+    bf16x8 *dst = img + (tn * 3) * 64 + lane;
+    dst[0] = p0; dst[64] = p1; dst[128] = p2;
+}
+
+__device__ __forceinline__ void act_split_bf3(long blk, const float *__restrict__ x, long V, int C,
+                                              const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                              bf16x8 *__restrict__ xs)
+{
+    const int C8 = C >> 3;
+    const long o = blk * 256 + threadIdx.x;          // (row, 8-channel group)
+    if (o >= V * C8) return;
+    const long row = o / C8;
+    const int c0 = (int)(o % C8) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(x + row * C + c0), b = *reinterpret_cast<const f32x4 *>(x + row * C + c0 + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float y = v[e];
+        if (scale) {
+            y = fmaf(y, scale[c0 + e], shift[c0 + e]);
+            if (relu) y = fmaxf(y, 0.f);
+        }
+        __bf16 h0, h1, h2;
+        split3(y, h0, h1, h2);
+        p0[e] = h0; p1[e] = h1; p2[e] = h2;
+    }
+    bf16x8 *dst = xs + (row * 3) * C8 + (c0 >> 3);
+    dst[0] = p0; dst[C8] = p1; dst[2 * C8] = p2;
+}
+
+// both passes in one launch: blocks [0, nblk_dout) lay dout out, the rest split the activated input
+__global__ __launch_bounds__(256) void wgrad_bf3_operands_kernel(const float *__restrict__ dout, const float *__restrict__ x, long V,
+                                                                 int Cin, int Cout, int NB, long ntile, int nblk_dout,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 int relu, bf16x8 *__restrict__ img, bf16x8 *__restrict__ xs)
+{
+    if ((int)blockIdx.x < nblk_dout) split_rows_bf3(blockIdx.x, dout, V, Cout, NB, ntile, img);
+    else act_split_bf3((long)blockIdx.x - nblk_dout, x, V, Cin, scale, shift, relu, xs);
+}
+
+struct WgradBf3Args {
+    const bf16x8 *xs;        // activated input pieces, row-major [Vin][3][Cin/8]
+    const bf16x8 *dout_img;  // dout operands [Vout/32][NB][3][64]
+    const int *nbr;          // [K][Vout]
+    float *partial;
+    int Vout, K, Cin, Cout, NBtot, rows_per_block;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int KG, int NW, int NBW>
+__global__ __launch_bounds__(64 * NW, 2) void spconv_wgrad_bf3_kernel(WgradBf3Args p)
+{
+    constexpr int NT = 64 * NW, TILE = 192;                  // a tile = 32 rows x (3 pieces x 2 halves) 16-byte words
+    constexpr int E = (KG * TILE + NT - 1) / NT;             // gather entries per thread and trip
+    __shared__ __attribute__((aligned(16))) short s_a[KG][3][32 * 16];          // [offset][piece][row][16 ch]
+    const int l = lane_id(), q = l >> 4, cl = l & 15, w = wave_id();
+    const int k0 = blockIdx.y * KG;
+    const int C8 = p.Cin >> 3;
+    f32x4 acc[KG][NBW];
+#pragma unroll
+    for (int a = 0; a < KG; a++)
+#pragma unroll
+        for (int b = 0; b < NBW; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r_begin = blockIdx.x * p.rows_per_block;
+    const int r_end = min(p.Vout, r_begin + p.rows_per_block);
+    const int rd0 = (8 * q + (cl >> 2)) * 16 + 4 * (cl & 3), rd1 = rd0 + 4 * 16;
+    // entry e of the workgroup's gather list: offset e / 192, row (e % 192) / 6, piece ((e % 6) >> 1), half e & 1 -- packed
+    // into one register per entry: bits 0-14 LDS slot (in 16-byte words... shorts / 8), 15-19 row, 20-27 source word, 28-32 offset
+    unsigned e_pk[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int e = threadIdx.x + i * NT;
+        const int kk = min(e / TILE, KG - 1), rem = e % TILE, row = rem / 6, pc = (rem % 6) >> 1, half = rem & 1;
+        const bool ok = e < KG * TILE && k0 + kk < p.K;
+        e_pk[i] = (unsigned)(((kk * 3 + pc) * 512 + row * 16 + half * 8) >> 3) | ((unsigned)row << 15)
+                  | ((unsigned)(pc * C8 + blockIdx.z * 2 + half) << 20) | ((unsigned)(ok ? kk : 15) << 28);
+    }
+    auto load_idx = [&](int r0, int (&idx)[E]) {
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const int row = r0 + (int)((e_pk[i] >> 15) & 31), kk = (int)(e_pk[i] >> 28);
+            const bool ok = kk != 15 && row < r_end;
+            const int v = p.nbr[(size_t)(k0 + (ok ? kk : 0)) * p.Vout + (ok ? row : r_begin)];
+            idx[i] = v | (ok ? 0 : -1);
+        }
+    };
+    auto gather = [&](const int (&idx)[E], uint4 (&g)[E]) {
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(p.xs)[(size_t)max(idx[i], 0) * 3 * C8 + ((e_pk[i] >> 20) & 255)];
+            const unsigned keep = idx[i] >= 0 ? 0xffffffffu : 0u;
+            g[i] = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+        }
+    };
+    auto load_b = [&](int r0, uint4 (&bw)[NBW][3]) {
+#pragma unroll
+        for (int j = 0; j < NBW; j++) {
+            const int nb = w * NBW + j;
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.dout_img) + (((size_t)(r0 >> 5) * p.NBtot + min(nb, p.NBtot - 1)) * 3) * 64 + l;
+            const bool ok = nb < p.NBtot && r0 < r_end;
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) bw[j][pc] = ok ? src[pc * 64] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    int idx_n[E];
+    uint4 g[E];
+    uint4 bw[NBW][3];
+    {
+        int idx_c[E];
+        load_idx(r_begin, idx_c);
+        gather(idx_c, g);
+    }
+    load_idx(r_begin + 32, idx_n);
+    load_b(r_begin, bw);
+    short *tiles = &s_a[0][0][0];
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();                         // everybody has read the previous trip's tiles
+#pragma unroll
+        for (int i = 0; i < E; i++)
+            if (E * NT == KG * TILE || threadIdx.x + i * NT < KG * TILE) *reinterpret_cast<uint4 *>(tiles + (e_pk[i] & 0x7fff) * 8) = g[i];
+        __syncthreads();
+        uint4 bc[NBW][3];
+#pragma unroll
+        for (int j = 0; j < NBW; j++)
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) bc[j][pc] = bw[j][pc];
+        // the next trip's operands fly during this trip's MFMAs
+        gather(idx_n, g);
+        load_idx(r0 + 64, idx_n);
+        load_b(r0 + 32, bw);
+#pragma unroll
+        for (int kk = 0; kk < KG; kk++) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) {
+                const short *tp = tiles + (kk * 3 + pc) * 512;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(tp + rd0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(tp + rd1));
+                short t8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[pc] = *reinterpret_cast<const bf16x8 *>(t8);
+            }
+#pragma unroll
+            for (int j = 0; j < NBW; j++) {
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&bc[j][0]), w1 = *reinterpret_cast<const bf16x8 *>(&bc[j][1]),
+                             w2 = *reinterpret_cast<const bf16x8 *>(&bc[j][2]);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], w0, acc[kk][j], 0, 0, 0);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], w2, acc[kk][j], 0, 0, 0);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], w1, acc[kk][j], 0, 0, 0);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], w0, acc[kk][j], 0, 0, 0);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], w1, acc[kk][j], 0, 0, 0);
+                acc[kk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], w0, acc[kk][j], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl
+    float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
+#pragma unroll
+    for (int kk = 0; kk < KG; kk++) {
+        const int k = k0 + kk;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int j = 0; j < NBW; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ci = blockIdx.z * 16 + 4 * q + r, col = 16 * (w * NBW + j) + cl;
+                if (ci < p.Cin && col < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + col] = acc[kk][j][r];
+            }
+    }
+}
+
+template <int KG, int NW, int NBW>
+int launch_wgrad_bf3(const WgradBf3Args &p, int nblk_rows, hipStream_t stream)
+{
+    dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
+    spconv_wgrad_bf3_kernel<KG, NW, NBW><<<grid, 64 * NW, 0, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // dW[e] = sum over row chunks of partial[b][e].  Block = 16 elements x 16 slab lanes: lane j sums slabs j, j+16, ...
 // and the 16 lane sums are combined in lane order -> fixed order, deterministic; 16x the threads of one-thread-per-
 // element (the slab walk is latency-bound: 251 slabs took 21 us).
@@ -2543,9 +2762,26 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     return MS3D_E_UNSUPPORTED;
 }
 
+static bool wgrad_bf3_ok(int Vout, int K, int Cin, int Cout, bool use_list)
+{
+    // below ~30 M row x channel x channel products the operand pass and the coarser row chunks cost more than the shorter
+    // MFMA sequence saves (measured: 80 ch @ 2.5k rows and 48 ch @ 11.7k rows lose, 128 @ 2.5k and 64 @ 11.7k win)
+    if ((double)Vout * Cin * Cout < 30e6) return false;
+    static const bool wg = [] { const char *e = getenv("MS3D_BF16X3_WGRAD"); return !e || atoi(e) != 0; }();
+    const int nb = ms3d_divup(Cout, 16);
+    // K == 27: submanifold tables, input rows = output rows (the exported entry point is not told the input row count)
+    return bf3_enabled() && wg && !use_list && K == 27 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin % 16 == 0 && Cout % 16 == 0;
+}
+int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_list) { return wgrad_bf3_ok(Vout, K, Cin, Cout, offset_list != 0) ? 1 : 0; }
+// slabs + (bf16x3 kernel) the dout operand image and the activated input pieces
 size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout)
 {
-    return (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout + 64;
+    size_t n = (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout + 64;
+    if (wgrad_bf3_ok(Vout, K, Cin, Cout, false)) {
+        n += (size_t)ms3d_divup(Vout, 32) * ms3d_divup(Cout, 16) * 3 * 64 * 4 + 8;        // dout image, 16 B units
+        n += (size_t)Vout * Cin * 3 / 2 + 8;                                                 // 6 B per input element
+    }
+    return n;
 }
 
 int ms3d_spconv_wgrad_row_chunks(int Vout)
@@ -2603,6 +2839,32 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
            : nb == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
            : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
+        if (rc) return rc;
+        launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    }
+    if (wgrad_bf3_ok(Vout, K, Cin, Cout, use_list)) {
+        // wide submanifold layers: both operands pre-split into three bf16 pieces by two elementwise passes
+        float *base = partial_ws + (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout;
+        bf16x8 *img = reinterpret_cast<bf16x8 *>((reinterpret_cast<uintptr_t>(base) + 15) & ~(uintptr_t)15);
+        const long ntile = ms3d_divup(Vout, 32);
+        bf16x8 *xs = img + (size_t)ntile * nb * 3 * 64;
+        const long t1 = ntile * nb * 64, t2 = (long)Vout * (Cin / 8);
+        const int nb1 = (int)((t1 + 255) / 256), nb2 = (int)((t2 + 255) / 256);
+        wgrad_bf3_operands_kernel<<<nb1 + nb2, 256, 0, stream>>>(dout, in, Vout, Cin, Cout, nb, ntile, nb1, pre_scale, pre_shift,
+                                                                pre_relu, img, xs);
+        MS3D_LAUNCH_CHECK();
+        WgradBf3Args q;
+        q.xs = xs; q.dout_img = img; q.nbr = nbr; q.partial = partial_ws; q.Vout = Vout; q.K = K; q.Cin = Cin; q.Cout = Cout;
+        q.NBtot = nb;
+        q.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 32) * 32;
+        nblk = ms3d_divup(Vout, q.rows_per_block);
+        // waves split the output columns (NW waves x NBW blocks of 16), a workgroup takes KG offsets
+        // (KG offsets per workgroup, waves, 16-column blocks per wave): the largest tiles that stay inside 256 registers at
+        // two workgroups per CU -- every larger one tried spills (profiles/r03_fwd_experiments.txt section 6)
+        rc = nb == 3 ? launch_wgrad_bf3<14, 3, 1>(q, nblk, stream) : nb == 4 ? launch_wgrad_bf3<14, 4, 1>(q, nblk, stream)
+           : nb <= 6 ? launch_wgrad_bf3<9, 3, 2>(q, nblk, stream) : launch_wgrad_bf3<9, 4, 2>(q, nblk, stream);
         if (rc) return rc;
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
         MS3D_LAUNCH_CHECK();

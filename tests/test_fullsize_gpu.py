@@ -484,7 +484,12 @@ def test_bf16x3_wide_layers_are_float32_grade(be, cin, cout, level):
     assert e_dx <= 3e-6
     want_dW = torch.stack([act[torch.where(nbr[k] >= 0, nbr[k], 0).long()].mul((nbr[k] >= 0)[:, None]).t() @ dy.double()
                            for k in range(K)])
-    assert ((dW.double() - want_dW).abs().max() / want_dW.abs().max()).item() <= 1e-5
+    e_dW = ((dW.double() - want_dW).abs().max() / want_dW.abs().max()).item()
+    # backward-weight (a sum over up to ~200k rows): three-piece operands on the wide layers with enough rows
+    # (spconv_wgrad_bf3_kernel), the exact-f32 kernel otherwise -- same bar for both, and the split one no worse than 1.5x
+    split_w = bool(be.lib.ms3d_spconv_wgrad_is_bf16x3(V, K, cin, cout, 0)) and max(cin, cout) > 64
+    print(f"{cin}->{cout}: backward-weight vs fp64 {e_dW:.2e} ({'bf16x3' if split_w else 'f32 MFMA'})")
+    assert e_dW <= 1e-5
 
 
 def test_scatter_add_rows_vs_index_add(be):

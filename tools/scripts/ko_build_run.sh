@@ -1,0 +1,5 @@
+# usage: bash tools/scripts/ko_build_run.sh "<-D flags>" "<conv_micro cfg>" ...   (experiment build of the library on the box)
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1
+FLAGS="$1"; shift
+MS3D_EXTRA_HIPCC_FLAGS="$FLAGS" python3 -c "from minsu3d_amd import build; build.build(force=True)" > /dev/null 2>&1 || echo BUILD FAILED
+for cfg in "$@"; do python3 tools/conv_micro.py $cfg 2>&1 | tail -1 | grep -o "cin=[0-9]* cout=[0-9]* K=[0-9]* vin=[0-9]*\|layer fwd [0-9.]* us\|wgrad [0-9.]* us" | tr '\n' ' '; echo; done
