@@ -65,6 +65,7 @@ struct ConvArgs {
     int NCH;    // ceil(Cin / 16)
     int NBtot;  // Cout / 16
     int G;      // offsets whose weights are LDS resident at once
+    int GC;     // bf16x3 table walk: 32-channel chunks of those offsets resident at once (0 = all)
     int ntiles;
     int pre_relu;
     const int *pl_tile_start;  // pair list of the table (ms3d_kmap_pairlist_build) or null
@@ -111,6 +112,47 @@ __device__ __forceinline__ void split3(float v, __bf16 &h0, __bf16 &h1, __bf16 &
     h1 = (__bf16)r1;
     const float r2 = r1 - (float)h1;  // exact
     h2 = (__bf16)r2;
+}
+
+// Eight gathered floats of a lane -> the three bf16x8 MFMA operands, with the fused prologue: y = x * s + b (when
+// `affine`), y = max(y, floor) (floor = 0 for ReLU, -inf otherwise: one instruction instead of max + select), absent
+// neighbours / padded channels zeroed by `keep`.  The split works on PAIRS: v_cvt_pk_bf16_f32 rounds two floats at once
+// and the rounded values come back as floats by a shift / a mask -- 11 instructions per pair against 16 of the
+// element-wise split3 (same roundings, same pieces).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b)
+{
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return *reinterpret_cast<const uint32_t *>(&h);
+}
+__device__ __forceinline__ void act_split8(const f32x4 &lo, const f32x4 &hi, bool affine, const f32x4 &s0, const f32x4 &s1,
+                                           const f32x4 &b0, const f32x4 &b1, float floor_, int keep, bf16x8 &a0, bf16x8 &a1,
+                                           bf16x8 &a2)
+{
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { v[t] = lo[t]; v[4 + t] = hi[t]; }
+    if (affine) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            v[t] = fmaxf(fmaf(v[t], s0[t], b0[t]), floor_);
+            v[4 + t] = fmaxf(fmaf(v[4 + t], s1[t], b1[t]), floor_);
+        }
+    }
+    uint32_t q0[4], q1[4], q2[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float x = __int_as_float(__float_as_int(v[2 * t]) & keep), y = __int_as_float(__float_as_int(v[2 * t + 1]) & keep);
+        q0[t] = cvt_pk_bf16(x, y);
+        const float rx = x - __uint_as_float(q0[t] << 16), ry = y - __uint_as_float(q0[t] & 0xffff0000u);     // exact
+        q1[t] = cvt_pk_bf16(rx, ry);
+        const float sx = rx - __uint_as_float(q1[t] << 16), sy = ry - __uint_as_float(q1[t] & 0xffff0000u);   // exact
+        q2[t] = cvt_pk_bf16(sx, sy);
+    }
+    a0 = *reinterpret_cast<const bf16x8 *>(q0);
+    a1 = *reinterpret_cast<const bf16x8 *>(q1);
+    a2 = *reinterpret_cast<const bf16x8 *>(q2);
 }
 
 __device__ __forceinline__ void write_bf3(float *aux, int k, int c, int j, int Cin_e, int NB, float v)
@@ -480,15 +522,20 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     }
 }
 
-// ---- table walk on the three-piece bf16 image (wide square layers, Cin and Cout multiples of 32) ----------------
-// Same geometry and epilogue as spconv_fwd_kernel: a wave owns 16 output rows x NBT column blocks, the block's column
-// slice of the weights is staged through LDS in groups of G offsets.  Per offset and 32-channel chunk a lane gathers
-// the 8 channels [32*c32 + 8*(lane >> 4), +8) of its row (two 16-byte loads), applies the fused BatchNorm / ReLU,
-// splits the 8 floats into three bf16 pieces (exact) and issues six v_mfma_f32_16x16x32_bf16 per column block --
-// x0w0, x0w1, x1w0, x1w1, x0w2, x2w0 -- into the f32 accumulator: float32-grade (tests: 1e-6 against the f32 kernel).
+// ---- table walk on the three-piece bf16 image (wide layers) -----------------------------------------------------
+// Same grid and epilogue as spconv_fwd_kernel: a wave owns 16 output rows x NBT column blocks, the block's column slice
+// of the weights goes through LDS.  Per offset and 32-channel chunk a lane gathers the 8 channels
+// [32*c32 + 8*(lane >> 4), +8) of its row (two 16-byte loads), applies the fused BatchNorm / ReLU, splits the 8 floats
+// into three bf16 pieces (exact) and issues six v_mfma_f32_16x16x32_bf16 per column block -- x0w0, x0w1, x1w0, x1w1,
+// x0w2, x2w0 -- into the f32 accumulator: float32-grade (tests: 3e-6 against float64, as the f32 kernel).
+// When the image does not fit, a STAGE is (OGB offsets) x (GC chunks): the gather rounds -- one per chunk, OGB rows in
+// flight per lane -- stay full however wide the layer is.  (Staging all chunks of G offsets left 128 -> 128 with one
+// offset per stage: four dependent one-row gather rounds between two barriers, 27 times.)  The first gather round of a
+// stage is issued BEFORE the stage's barrier and weight copy, the index group of the next offsets one group ahead.
 constexpr int OGB = 5;   // offsets per gather group: 10 x 16 B per lane in flight
 
-template <int NBT>
+// OG: offsets per gather round / stage (bf3_round_offsets(NBT): the most that stays inside the 128 registers of a 1024-thread block)
+template <int NBT, int OG>
 __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
 {
     extern __shared__ float lds[];
@@ -496,15 +543,18 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     const int waves = blockDim.x >> 6;
     const int nb0 = blockIdx.y * NBT;
     const int NC32 = (p.Cin + 31) >> 5;
-    uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][c32][nb][piece][lane] x 16 B
-    float *s_part = lds + (size_t)p.G * NC32 * NBT * 3 * 64 * 4;           // [2*Cout] when statistics are asked for
+    const int GC = p.GC > 0 ? p.GC : NC32;                                  // chunks per stage
+    uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][chunk in range][nb][piece][lane] x 16 B
+    float *s_part = lds + (size_t)p.G * GC * NBT * 3 * 64 * 4;             // [2*Cout] when statistics are asked for
     const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
     const int slab = NBT * 3 * 64;                                          // uint4 per (offset, c32) in the LDS image
-    auto stage = [&](int k_lo, int cnt) {
-        const int rows = cnt * NC32;
+    // offsets [k_lo, k_lo + cnt) x chunks [c_lo, c_lo + ccnt) of this block's column slice
+    auto stage = [&](int k_lo, int cnt, int c_lo, int ccnt) {
+        const int rows = cnt * ccnt;
         for (int e = threadIdx.x; e < rows * slab; e += blockDim.x) {
             const int r = e / slab, c = e - r * slab;
-            sW[e] = img[((size_t)(k_lo * NC32 + r) * p.NBtot + nb0) * 3 * 64 + c];
+            const int kk = r / ccnt, cc = r - kk * ccnt;
+            sW[e] = img[((size_t)((k_lo + kk) * NC32 + c_lo + cc) * p.NBtot + nb0) * 3 * 64 + c];
         }
     };
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
@@ -515,106 +565,98 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     const int per_xcd = (nblk + 7) / 8;
     int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (nblk % 8 != 0) vb = blockIdx.x;  // only remap when it is a bijection
+    const bool affine = p.pre_scale != nullptr;
+    const float relu_floor = p.pre_relu ? 0.f : -INFINITY;
 
-    // offsets [k_lo, k_hi) of one tile against the staged group that starts at offset g0
-    auto accumulate = [&](int g0, int k_lo, int k_hi, int my_row, f32x4 (&acc)[NBT]) {
+    // table entries of offsets [k0, k0 + OG) n [.., k_end) for this lane's row
+    auto load_idx = [&](int k0, int k_end, int my_row, int (&idx)[OG]) {
         const bool row_ok = my_row < p.Vout;
         const int safe_row = row_ok ? my_row : 0;
-        for (int k0 = k_lo; k0 < k_hi; k0 += OGB) {
-            int idx[OGB];
 #pragma unroll
-            for (int u = 0; u < OGB; u++) {
-                const int k = min(k0 + u, k_hi - 1);
-                const int v = p.nbr[(size_t)k * p.Vout + safe_row];
-                idx[u] = v | ((row_ok && k0 + u < k_hi) ? 0 : -1);
-            }
-            bool any[OGB];
+        for (int u = 0; u < OG; u++) {
+            const int k = min(k0 + u, p.K - 1);
+            const int v = p.nbr[(size_t)k * p.Vout + safe_row];
+            idx[u] = v | ((row_ok && k0 + u < k_end) ? 0 : -1);
+        }
+    };
+    // one round: this lane's 8 channels of chunk c32 for the OG rows (unconditional, clamped: a branch around a gather
+    // drains the counter)
+    struct Round { f32x4 lo[OG], hi[OG]; };
+    auto gather = [&](int c32, const int (&idx)[OG], Round &r) {
+        const int cr = 32 * c32 + 8 * g8;
+        const int c0 = cr < p.Cin ? cr : p.Cin - 8;
 #pragma unroll
-            for (int u = 0; u < OGB; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
-            for (int c32 = 0; c32 < NC32; c32++) {
-                const int cr = 32 * c32 + 8 * g8;
-                const int c_keep = cr < p.Cin ? -1 : 0;     // Cin = 48, 80, 112: the upper half of the last chunk is padding
-                const int c0 = cr < p.Cin ? cr : p.Cin - 8;
-                f32x4 lo[OGB], hi[OGB];
+        for (int u = 0; u < OG; u++) {
+            const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
+            r.lo[u] = *reinterpret_cast<const f32x4 *>(row);
+            r.hi[u] = *reinterpret_cast<const f32x4 *>(row + 4);
+        }
+    };
+    // the MFMAs of one round against LDS slabs [(u * cstride + cslot)]
+    auto compute = [&](int c32, int cslot, int cstride, const int (&idx)[OG], const bool (&any)[OG], const Round &r,
+                       f32x4 (&acc)[NBT]) {
+        const int cr = 32 * c32 + 8 * g8;
+        const int c_keep = cr < p.Cin ? -1 : 0;     // Cin = 48, 80, 112: the upper half of the last chunk is padding
+        const int c0 = cr < p.Cin ? cr : p.Cin - 8;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, b0 = s0, b1 = s0;
+        if (affine) {
+            s0 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0); s1 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0 + 4);
+            b0 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0); b1 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0 + 4);
+        }
 #pragma unroll
-                for (int u = 0; u < OGB; u++) {     // unconditional, clamped (a branch around a gather drains the counter)
-                    const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
-                    lo[u] = *reinterpret_cast<const f32x4 *>(row);
-                    hi[u] = *reinterpret_cast<const f32x4 *>(row + 4);
-                }
-                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, b0 = s0, b1 = s0;
-                if (p.pre_scale) {
-                    s0 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0); s1 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0 + 4);
-                    b0 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0); b1 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0 + 4);
-                }
+        for (int u = 0; u < OG; u++) {
+            if (!any[u]) continue;
+            bf16x8 a0, a1, a2;
+            // absent neighbour (idx < 0) / padded channels contribute nothing
+            act_split8(r.lo[u], r.hi[u], affine, s0, s1, b0, b1, relu_floor, ~(idx[u] >> 31) & c_keep, a0, a1, a2);
+            const uint4 *w = sW + (size_t)(u * cstride + cslot) * slab + l;
 #pragma unroll
-                for (int u = 0; u < OGB; u++) {
-                    if (!any[u]) continue;
-                    float v[8];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { v[t] = lo[u][t]; v[4 + t] = hi[u][t]; }
-                    if (p.pre_scale) {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const float x0 = fmaf(v[t], s0[t], b0[t]), x1 = fmaf(v[4 + t], s1[t], b1[t]);
-                            v[t] = p.pre_relu ? fmaxf(x0, 0.f) : x0;
-                            v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
-                        }
-                    }
-                    const int keep = ~(idx[u] >> 31) & c_keep;   // absent neighbour (idx < 0) / padded channels contribute nothing
-                    bf16x8 a0, a1, a2;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        __bf16 h0, h1, h2;
-                        split3(__int_as_float(__float_as_int(v[e]) & keep), h0, h1, h2);
-                        a0[e] = h0; a1[e] = h1; a2[e] = h2;
-                    }
-                    const uint4 *w = sW + (size_t)((k0 - g0 + u) * NC32 + c32) * slab + l;
-#pragma unroll
-                    for (int nb = 0; nb < NBT; nb++) {
-                        const uint4 r0 = w[(nb * 3 + 0) * 64], r1 = w[(nb * 3 + 1) * 64], r2 = w[(nb * 3 + 2) * 64];
-                        const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&r0), w1 = *reinterpret_cast<const bf16x8 *>(&r1),
-                                     w2 = *reinterpret_cast<const bf16x8 *>(&r2);
-                        // smallest terms first
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w0, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w2, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w1, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc[nb], 0, 0, 0);
-                    }
-                }
+            for (int nb = 0; nb < NBT; nb++) {
+                const uint4 r0 = w[(nb * 3 + 0) * 64], r1 = w[(nb * 3 + 1) * 64], r2 = w[(nb * 3 + 2) * 64];
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&r0), w1 = *reinterpret_cast<const bf16x8 *>(&r1),
+                             w2 = *reinterpret_cast<const bf16x8 *>(&r2);
+                // smallest terms first
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w0, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w2, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc[nb], 0, 0, 0);
             }
         }
     };
 
-    if (p.G >= p.K) {
-        stage(0, p.K);
-        __syncthreads();
-        const int total_waves = nblk * waves;
-        const int chunk = (p.ntiles + total_waves - 1) / total_waves;
-        const int wglobal = vb * waves + wave_id();
-        const int t_begin = wglobal * chunk, t_end = min(p.ntiles, t_begin + chunk);
-        for (int tile = t_begin; tile < t_end; tile++) {
-            const int row0 = tile * 16;
-            f32x4 acc[NBT];
-#pragma unroll
-            for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            accumulate(0, 0, p.K, row0 + (l & 15), acc);
-            store_tile<NBT>(p, row0, nb0, acc, s_part);
-        }
-    } else {
+    {
+        // one tile per wave, accumulators stay in registers; p.G = OG offsets x GC chunks per stage
         const int tile = vb * waves + wave_id();
-        const int row0 = tile * 16;
+        const int row0 = tile * 16, my_row = row0 + (l & 15);
         f32x4 acc[NBT];
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int g0 = 0; g0 < p.K; g0 += p.G) {
-            const int gn = min(p.G, p.K - g0);
-            __syncthreads();
-            stage(g0, gn);
-            __syncthreads();
-            if (tile < p.ntiles) accumulate(g0, g0, g0 + gn, row0 + (l & 15), acc);
+        int idx[OG];
+        load_idx(0, min(p.G, p.K), my_row, idx);
+        for (int k0 = 0; k0 < p.K; k0 += p.G) {
+            const int gn = min(p.G, p.K - k0);
+            int idx_n[OG];
+            load_idx(k0 + p.G, min(k0 + 2 * p.G, p.K), my_row, idx_n);      // the next group's table entries, a whole group ahead
+            bool any[OG];
+#pragma unroll
+            for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
+            for (int c_lo = 0; c_lo < NC32; c_lo += GC) {
+                const int ccnt = min(GC, NC32 - c_lo);
+                Round r;
+                gather(c_lo, idx, r);            // in flight across the barrier and the weight copy
+                __syncthreads();
+                stage(k0, gn, c_lo, ccnt);
+                __syncthreads();
+                if (tile < p.ntiles) compute(c_lo, 0, ccnt, idx, any, r, acc);
+                for (int cc = 1; cc < ccnt; cc++) {
+                    gather(c_lo + cc, idx, r);
+                    if (tile < p.ntiles) compute(c_lo + cc, cc, ccnt, idx, any, r, acc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OG; u++) idx[u] = idx_n[u];
         }
         if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
@@ -625,12 +667,16 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     }
 }
 
+// measured per column count (profiles/r03_fwd_experiments.txt section 9)
+constexpr int bf3_round_offsets(int nbt) { return nbt == 2 || nbt == 4 || nbt == 6 ? 5 : 4; }
+
 template <int NBT>
 int launch_fwd_bf3(const ConvArgs &p, dim3 grid, int threads, size_t lds, hipStream_t stream)
 {
-    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_bf3_kernel<NBT>);
+    constexpr int OG = bf3_round_offsets(NBT);
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_bf3_kernel<NBT, OG>);
     MS3D_CHECK(attr);
-    spconv_fwd_bf3_kernel<NBT><<<grid, threads, lds, stream>>>(p);
+    spconv_fwd_bf3_kernel<NBT, OG><<<grid, threads, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -748,26 +794,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
 #pragma unroll
             for (int u = 0; u < OGB; u++) {
                 bf16x8 a0, a1, a2;
-                if (any[u]) {
-                    float v[8];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { v[t] = lo[u][t]; v[4 + t] = hi[u][t]; }
-                    if (p.pre_scale) {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const float x0 = fmaf(v[t], s0[t], b0[t]), x1 = fmaf(v[4 + t], s1[t], b1[t]);
-                            v[t] = p.pre_relu ? fmaxf(x0, 0.f) : x0;
-                            v[4 + t] = p.pre_relu ? fmaxf(x1, 0.f) : x1;
-                        }
-                    }
-                    const int keep = ~(idx[u] >> 31) & c_keep;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        __bf16 h0, h1, h2;
-                        split3(__int_as_float(__float_as_int(v[e]) & keep), h0, h1, h2);
-                        a0[e] = h0; a1[e] = h1; a2[e] = h2;
-                    }
-                }
+                if (any[u])
+                    act_split8(lo[u], hi[u], p.pre_scale != nullptr, s0, s1, b0, b1, p.pre_relu ? 0.f : -INFINITY,
+                               ~(idx[u] >> 31) & c_keep, a0, a1, a2);
 #pragma unroll
                 for (int cg = 0; cg < NG; cg++) {
                     constexpr int dummy = 0; (void)dummy;
@@ -2729,15 +2758,21 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     if (aux_kind == 2 && wf_stream && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2) {
         // same grid as the f32 table walk (the statistics partials are sized for it); only the staged group shrinks:
         // three bf16 pieces are 6 bytes per weight
-        const size_t per_offset = (size_t)((Cin + 31) / 32) * g.nbt * 3 * 1024;
+        const int nc32 = (Cin + 31) / 32;
+        const size_t per_slab = (size_t)g.nbt * 3 * 1024;                 // one (offset, 32-channel chunk) of the slice
         const size_t extra = (bn_x != nullptr || p.out_stats) ? 2 * (size_t)Cout * sizeof(float) : 0;
-        int G = (int)((LDS_BUDGET - extra) / per_offset);
-        if (G > K) G = K;
-        const bool was_resident = g.G >= K;
-        if (G >= 1 && (!was_resident || G >= K)) {
+        const int slabs = (int)((LDS_BUDGET - extra) / per_slab);
+        // a stage = one gather round's offsets x as many chunks as fit beside them.  (Layers whose f32 image is LDS
+        // resident keep the f32 kernel: its grid is the persistent one.)
+        const int og = bf3_round_offsets(g.nbt);
+        const int go = K < og ? K : og;       // (2..5 offsets per stage measured within 3 % of each other)
+        int gc = slabs / go;
+        if (gc > nc32) gc = nc32;
+        if (g.G < K && gc >= 1) {
             p.wfb = wf_stream;
-            p.G = G;
-            const size_t lds = per_offset * G + extra;
+            p.G = go;
+            p.GC = gc;
+            const size_t lds = per_slab * p.G * p.GC + extra;
             switch (g.nbt) {
                 case 2: return launch_fwd_bf3<2>(p, grid, g.threads, lds, stream);
                 case 3: return launch_fwd_bf3<3>(p, grid, g.threads, lds, stream);
