@@ -66,6 +66,7 @@ struct ConvArgs {
     int NBtot;  // Cout / 16
     int G;      // offsets whose weights are LDS resident at once
     int GC;     // bf16x3 table walk: 32-channel chunks of those offsets resident at once (0 = all)
+    int RT;     // small levels: 16-row tiles per block (0 / 1 = one)
     int ntiles;
     int pre_relu;
     const int *pl_tile_start;  // pair list of the table (ms3d_kmap_pairlist_build) or null
@@ -698,27 +699,34 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
     if (with_partial) {
         for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
     }
-    const int tile = blockIdx.x;
-    const int row0 = tile * 16, my_row = row0 + (l & 15);
-    f32x4 acc[NBT];
+    // p.RT > 1: the geometry was laid out for the bf16x3 RT-tile kernel but this call has no bf16x3 image (the exact-f32
+    // entry point on a wide layer): the same blocks take their RT tiles one after the other
+    const int rt = p.RT > 1 ? p.RT : 1;
+    for (int tt = 0; tt < rt; tt++) {
+        const int tile = blockIdx.x * rt + tt;
+        if (tile >= p.ntiles) break;
+        const int row0 = tile * 16, my_row = row0 + (l & 15);
+        f32x4 acc[NBT];
 #pragma unroll
-    for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int k_lo = wave_id() * OG, k_hi = min(p.K, k_lo + OG);
-    if (k_lo < k_hi) accumulate_offsets<NBT, ALIGNED, true>(p, nullptr, k_lo, k_hi, 0, my_row, q, nb0, acc);
-    if (wave_id() > 0) {
-#pragma unroll
-        for (int nb = 0; nb < NBT; nb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) s_acc[((size_t)(wave_id() - 1) * NBT + nb) * 256 + r * 64 + l] = acc[nb][r];
-    }
-    __syncthreads();
-    if (wave_id() == 0) {
-        for (int w = 1; w < waves; w++)
+        for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int k_lo = wave_id() * OG, k_hi = min(p.K, k_lo + OG);
+        if (k_lo < k_hi) accumulate_offsets<NBT, ALIGNED, true>(p, nullptr, k_lo, k_hi, 0, my_row, q, nb0, acc);
+        if (tt > 0) __syncthreads();          // wave 0 is done with the previous tile's partials
+        if (wave_id() > 0) {
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[nb][r] += s_acc[((size_t)(w - 1) * NBT + nb) * 256 + r * 64 + l];
-        store_tile<NBT>(p, row0, nb0, acc, s_part);
+                for (int r = 0; r < 4; r++) s_acc[((size_t)(wave_id() - 1) * NBT + nb) * 256 + r * 64 + l] = acc[nb][r];
+        }
+        __syncthreads();
+        if (wave_id() == 0) {
+            for (int w = 1; w < waves; w++)
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[nb][r] += s_acc[((size_t)(w - 1) * NBT + nb) * 256 + r * 64 + l];
+            store_tile<NBT>(p, row0, nb0, acc, s_part);
+        }
     }
     if (with_partial) {
         __syncthreads();
@@ -846,6 +854,178 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
         float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
         for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
     }
+}
+
+// ---- the same with RT row tiles per block (levels of ~3k - 17k rows) ------------------------------------------
+// With one 16-row tile per block every tile streams the whole weight image out of L2 (128 -> 128 at 12k rows: 754
+// blocks x 2.6 MB = 2 GB per launch, ~160 us at the L2's rate for 25 us of matrix work).  Here a block owns RT
+// consecutive tiles: a wave walks its share of the offsets one (offset, 32-channel chunk) step at a time, loads that
+// step's B operands ONCE (two column groups, double-buffered in registers: the next group's / next step's loads fly
+// during this group's MFMAs) and uses them for all RT tiles; the next step's gathers and the table entries of the offset
+// after are in flight during the step.  Partial accumulators of the waves meet in LDS; wave t finishes tile t.
+template <int NBT, int RT>
+__global__ __launch_bounds__(256) void spconv_fwd_small_bf3_rt_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    constexpr int CG = (NBT + 1) / 2;              // column blocks per operand group; always two groups
+    const int l = lane_id(), g8 = l >> 4;
+    const int waves = blockDim.x >> 6, w = wave_id();
+    const int nb0 = blockIdx.y * NBT;
+    const int NC32 = (p.Cin + 31) >> 5;
+    float *s_acc = lds;                                             // [waves][RT][NBT][4][64]
+    float *s_part = lds + (size_t)waves * RT * NBT * 256;          // [2*Cout] when bn_x / out_stats
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) {
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
+    }
+    const int tile0 = blockIdx.x * RT;
+    int safe_row[RT];
+    bool row_ok[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int r = (tile0 + t) * 16 + (l & 15);
+        row_ok[t] = r < p.Vout;
+        safe_row[t] = row_ok[t] ? r : 0;
+    }
+    f32x4 acc[RT][NBT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
+    const int ogw = (p.K + waves - 1) / waves;                     // offsets per wave
+    const int k_lo = w * ogw, k_hi = min(p.K, k_lo + ogw);
+    const int nsteps = max(0, k_hi - k_lo) * NC32;                 // step = (offset, 32-channel chunk)
+    const bool affine = p.pre_scale != nullptr;
+    const float relu_floor = p.pre_relu ? 0.f : -INFINITY;
+
+    auto load_idx = [&](int k, int (&idx)[RT]) {
+        const bool valid = k < k_hi;
+        const int kk = min(k, p.K - 1);
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            const int v = p.nbr[(size_t)kk * p.Vout + safe_row[t]];
+            idx[t] = v | ((row_ok[t] && valid) ? 0 : -1);
+        }
+    };
+    struct Rows { f32x4 lo[RT], hi[RT]; };
+    auto gather = [&](int c32, const int (&idx)[RT], Rows &g) {
+        const int cr = 32 * c32 + 8 * g8;
+        const int c0 = cr < p.Cin ? cr : p.Cin - 8;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            const float *row = p.in + (size_t)max(idx[t], 0) * p.Cin + c0;
+            g.lo[t] = *reinterpret_cast<const f32x4 *>(row);
+            g.hi[t] = *reinterpret_cast<const f32x4 *>(row + 4);
+        }
+    };
+    auto load_b = [&](int k, int c32, int cg, uint4 (&dst)[CG * 3]) {
+        const int kk = min(k, p.K - 1), first = cg * CG;
+        const uint4 *src = img + ((size_t)(kk * NC32 + c32) * p.NBtot + nb0 + first) * 3 * 64 + l;
+#pragma unroll
+        for (int i = 0; i < CG * 3; i++) dst[i] = src[min(i, (NBT - first) * 3 - 1) * 64];
+    };
+
+    int idx_c[RT], idx_n[RT];
+    Rows g_c;
+    uint4 wb[2][CG * 3];
+    load_idx(k_lo, idx_c);
+    gather(0, idx_c, g_c);
+    load_idx(k_lo + 1, idx_n);
+    load_b(k_lo, 0, 0, wb[0]);
+    int k = k_lo, c32 = 0;
+    for (int s = 0; s < nsteps; s++) {
+        const bool wrap = c32 + 1 == NC32;
+        const int c32n = wrap ? 0 : c32 + 1, kn = wrap ? k + 1 : k;
+        // next step's rows (clamped row 0 behind the last step)
+        Rows g_n;
+        if (wrap) gather(0, idx_n, g_n);
+        else gather(c32n, idx_c, g_n);
+        const int cr = 32 * c32 + 8 * g8;
+        const int c_keep = cr < p.Cin ? -1 : 0;
+        const int c0 = cr < p.Cin ? cr : p.Cin - 8;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, b0 = s0, b1 = s0;
+        if (affine) {
+            s0 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0); s1 = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0 + 4);
+            b0 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0); b1 = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0 + 4);
+        }
+        bf16x8 a[RT][3];
+        bool any[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            any[t] = __ballot(idx_c[t] >= 0) != 0ull;
+            if (any[t])
+                act_split8(g_c.lo[t], g_c.hi[t], affine, s0, s1, b0, b1, relu_floor, ~(idx_c[t] >> 31) & c_keep, a[t][0], a[t][1],
+                           a[t][2]);
+        }
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++) {
+            // the other operand set: this step's second column group, or the next step's first
+            if (cg == 0) load_b(k, c32, 1, wb[1]);
+            else load_b(kn, c32n, 0, wb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CG; i++) {
+                const int nb = cg * CG + i;
+                if (nb >= NBT) continue;
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(&wb[cg][i * 3 + 0]), w1 = *reinterpret_cast<const bf16x8 *>(&wb[cg][i * 3 + 1]),
+                             w2 = *reinterpret_cast<const bf16x8 *>(&wb[cg][i * 3 + 2]);
+#pragma unroll
+                for (int t = 0; t < RT; t++) {
+                    if (!any[t]) continue;
+                    f32x4 &d = acc[t][nb];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][2], w0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][0], w2, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][1], w1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][1], w0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][0], w1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][0], w0, d, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; t++) { g_c.lo[t] = g_n.lo[t]; g_c.hi[t] = g_n.hi[t]; }
+        if (wrap) {
+#pragma unroll
+            for (int t = 0; t < RT; t++) idx_c[t] = idx_n[t];
+            load_idx(kn + 1, idx_n);
+        }
+        k = kn; c32 = c32n;
+    }
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_acc[(((size_t)w * RT + t) * NBT + nb) * 256 + r * 64 + l] = acc[t][nb][r];
+    __syncthreads();
+    for (int t = w; t < RT; t += waves) {
+        if (tile0 + t >= p.ntiles) break;
+        f32x4 sum[NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) sum[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ww = 0; ww < waves; ww++)
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) sum[nb][r] += s_acc[(((size_t)ww * RT + t) * NBT + nb) * 256 + r * 64 + l];
+        store_tile<NBT>(p, (tile0 + t) * 16, nb0, sum, s_part);
+    }
+    if (with_partial) {
+        __syncthreads();
+        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
+    }
+}
+
+template <int NBT, int RT>
+int launch_fwd_small_bf3_rt(const ConvArgs &p, dim3 grid, int threads, size_t lds, hipStream_t stream)
+{
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_small_bf3_rt_kernel<NBT, RT>);
+    MS3D_CHECK(attr);
+    spconv_fwd_small_bf3_rt_kernel<NBT, RT><<<grid, threads, lds, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int NBT>
@@ -2433,7 +2613,9 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
 }  // extern "C"
 
 namespace {
+bool bf3_enabled();
 struct FwdGeom {
+    int rt;   // small levels on the bf16x3 image: 16-row tiles per block (1 = the one-tile kernels)
     int nbt, ny, threads, nblk, G;
     size_t lds;
     bool ok, small, pairlist, stream;
@@ -2519,8 +2701,25 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         g.threads = ks * 64;
         g.nblk = ntiles;
         g.G = K;
+        g.rt = 1;
         g.lds = ((size_t)(ks - 1) * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
         g.ok = ks <= 4 && g.nbt >= 1 && g.nbt <= MAX_NBT;
+        // bf16x3 layers with three or more rounds of one-tile blocks: three tiles per block share every weight load
+        // (spconv_fwd_small_bf3_rt_kernel) and one block per CU remains.  Measured at 11.7k rows, us per launch with 1 / 2 /
+        // 3 tiles per block: 128 -> 128 140 / 153 / 91, 96 -> 96 78 / 100 / 60, 112 -> 112 121 / 138 / 80, 64 -> 128
+        // 74 / 82 / 49, 64 -> 64 40 / 41 / 38 (two tiles leave 1.5 rounds of blocks); column-split levels (160 -> 160 at
+        // 2.5k rows) lose: 60 / 73 / 69.
+        static const int env_rt = [] { const char *e = getenv("MS3D_SMALL_RT"); return e ? atoi(e) : 3; }();
+        if (bf3_enabled() && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2 && K >= 4 && ny == 1) {
+            const int rt = (ntiles >= 3 * 230 && env_rt >= 3) ? 3 : 1;
+            if (rt > 1) {
+                const int waves = 4;
+                g.rt = rt;
+                g.threads = waves * 64;
+                g.nblk = ms3d_divup(ntiles, rt);
+                g.lds = ((size_t)waves * rt * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
+            }
+        }
         return g;
     }
     if (with_pairlist && pairstream_shape_ok(Vout, K, Cin, Cout)) {
@@ -2728,6 +2927,17 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
         if (g.nbt == 2 && p.NCH == 2) return launch_fwd_pairlist<2, 2>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 3) return launch_fwd_pairlist<1, 3>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 4) return launch_fwd_pairlist<1, 4>(p, grid, g.threads, g.lds, stream);
+        return MS3D_E_UNSUPPORTED;
+    }
+    p.RT = g.small ? g.rt : 1;
+    if (g.small && g.rt > 1 && aux_kind == 2 && wf_stream) {
+        // the geometry (and the caller's statistics partials) count RT tiles per block
+        p.wfb = wf_stream;
+#define MS3D_RT_CASE(N) case N: return launch_fwd_small_bf3_rt<N, 3>(p, grid, g.threads, g.lds, stream);
+        switch (g.nbt) {
+            MS3D_RT_CASE(2) MS3D_RT_CASE(3) MS3D_RT_CASE(4) MS3D_RT_CASE(5) MS3D_RT_CASE(6) MS3D_RT_CASE(7) MS3D_RT_CASE(8)
+        }
+#undef MS3D_RT_CASE
         return MS3D_E_UNSUPPORTED;
     }
     if (g.small && aux_kind == 2 && wf_stream && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2) {
