@@ -546,16 +546,22 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     const int NC32 = (p.Cin + 31) >> 5;
     const int GC = p.GC > 0 ? p.GC : NC32;                                  // chunks per stage
     uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][chunk in range][nb][piece][lane] x 16 B
-    float *s_part = lds + (size_t)p.G * GC * NBT * 3 * 64 * 4;             // [2*Cout] when statistics are asked for
-    const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
     const int slab = NBT * 3 * 64;                                          // uint4 per (offset, c32) in the LDS image
-    // offsets [k_lo, k_lo + cnt) x chunks [c_lo, c_lo + ccnt) of this block's column slice
+    float *s_part = lds + (size_t)p.G * GC * slab * 4;                      // [2*Cout] when statistics are asked for
+    const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
+    // offsets [k_lo, k_lo + cnt) x chunks [c_lo, c_lo + ccnt) of this block's column slice, copied by
+    // global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS at a wave-uniform base -- no registers, a handful of
+    // address instructions per KB (the per-element index arithmetic of a register copy was a quarter of the kernel's VALU
+    // work), completion on vmcnt (tools/probe/lds_direct_probe.hip checks the lane -> address mapping)
     auto stage = [&](int k_lo, int cnt, int c_lo, int ccnt) {
-        const int rows = cnt * ccnt;
-        for (int e = threadIdx.x; e < rows * slab; e += blockDim.x) {
-            const int r = e / slab, c = e - r * slab;
+        uint4 *dst = sW;
+        const int chunks = cnt * ccnt * NBT * 3;                            // 1 KB each
+        for (int ch = wave_id(); ch < chunks; ch += waves) {
+            const int r = ch / (NBT * 3), within = ch - r * (NBT * 3);
             const int kk = r / ccnt, cc = r - kk * ccnt;
-            sW[e] = img[((size_t)((k_lo + kk) * NC32 + c_lo + cc) * p.NBtot + nb0) * 3 * 64 + c];
+            const uint4 *src = img + ((size_t)((k_lo + kk) * NC32 + c_lo + cc) * p.NBtot + nb0) * 3 * 64 + within * 64 + l;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + (size_t)ch * 64), 16, 0, 0);
         }
     };
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
@@ -646,9 +652,10 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
             for (int c_lo = 0; c_lo < NC32; c_lo += GC) {
                 const int ccnt = min(GC, NC32 - c_lo);
                 Round r;
-                gather(c_lo, idx, r);            // in flight across the barrier and the weight copy
+                gather(c_lo, idx, r);            // in flight across the barrier (and the weight copy)
                 __syncthreads();
                 stage(k0, gn, c_lo, ccnt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share has landed (and its gathers)
                 __syncthreads();
                 if (tile < p.ntiles) compute(c_lo, 0, ccnt, idx, any, r, acc);
                 for (int cc = 1; cc < ccnt; cc++) {
@@ -2975,8 +2982,9 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
         // a stage = one gather round's offsets x as many chunks as fit beside them.  (Layers whose f32 image is LDS
         // resident keep the f32 kernel: its grid is the persistent one.)
         const int og = bf3_round_offsets(g.nbt);
-        const int go = K < og ? K : og;       // (2..5 offsets per stage measured within 3 % of each other)
-        int gc = slabs / go;
+        int go = K < og ? K : og;       // (2..5 offsets per stage measured within 3 % of each other)
+        if (go > slabs) go = slabs;
+        int gc = go >= 1 ? slabs / go : 0;
         if (gc > nc32) gc = nc32;
         if (g.G < K && gc >= 1) {
             p.wfb = wf_stream;
