@@ -2714,10 +2714,10 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         // bf16x3 layers with three or more rounds of one-tile blocks: three tiles per block share every weight load
         // (spconv_fwd_small_bf3_rt_kernel) and one block per CU remains.  Measured at 11.7k rows, us per launch with 1 / 2 /
         // 3 tiles per block: 128 -> 128 140 / 153 / 91, 96 -> 96 78 / 100 / 60, 112 -> 112 121 / 138 / 80, 64 -> 128
-        // 74 / 82 / 49, 64 -> 64 40 / 41 / 38 (two tiles leave 1.5 rounds of blocks); column-split levels (160 -> 160 at
-        // 2.5k rows) lose: 60 / 73 / 69.
+        // 74 / 82 / 49, 64 -> 64 40 / 41 / 38 (two tiles leave 1.5 rounds of blocks); levels with fewer tiles (160 -> 160 at
+        // 2.5k rows, five column slices) lose: 60 / 73 / 69.
         static const int env_rt = [] { const char *e = getenv("MS3D_SMALL_RT"); return e ? atoi(e) : 3; }();
-        if (bf3_enabled() && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2 && K >= 4 && ny == 1) {
+        if (bf3_enabled() && bf3_dims_ok(K, Cin, Cout) && g.nbt >= 2 && K >= 4) {
             const int rt = (ntiles >= 3 * 230 && env_rt >= 3) ? 3 : 1;
             if (rt > 1) {
                 const int waves = 4;
