@@ -1,5 +1,5 @@
 // Device-wide exclusive prefix sum of int32 (three short launches: per-span scan, span-sum
-// scan, carry add).  Used by the ball query (cell starts, list starts), the BFS output
+// scan, carry add; one launch up to 8192 elements).  Used by the ball query (cell starts, list starts), the BFS output
 // assembly and the coordinate engine.  Spans are contiguous so every load/store is coalesced.
 #include "common.h"
 #include "scan.h"
@@ -10,6 +10,7 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 4;                           // per thread per tile
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;    // 1024
 constexpr int SCAN_MAX_SPANS = 1024;
+constexpr int SCAN_ONE_BLOCK = 8 * SCAN_TILE;           // up to here one block scans the whole input
 
 __device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_wave)
 {
@@ -29,7 +30,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_wave)
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_spans_kernel(const int *in, int *out /* may alias in */, int n, int span,
-                                                                  int *__restrict__ span_sums)
+                                                                  int *__restrict__ span_sums, int *__restrict__ total_out)
 {
     __shared__ int s_wave[SCAN_THREADS / 64];
     const long begin = (long)blockIdx.x * span;
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spans_kernel(const int *in,
         }
         carry += tot;
     }
-    if (threadIdx.x == 0) span_sums[blockIdx.x] = carry;
+    if (threadIdx.x == 0) {
+        span_sums[blockIdx.x] = carry;
+        if (total_out) *total_out = carry;      // single-span launch: this block saw everything
+    }
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(int *__restrict__ span_sums, int nspans,
@@ -99,12 +103,18 @@ int ms3d_exclusive_scan_i32(const int *in, int *out, int n, int *total_out_dev, 
         if (total_out_dev) MS3D_CHECK(hipMemsetAsync(total_out_dev, 0, sizeof(int), stream));
         return 0;
     }
+    if (n <= SCAN_ONE_BLOCK) {
+        // short inputs (tile starts, per-cluster counts): one block walks all of it -- one launch instead of three
+        scan_spans_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, out, n, ms3d_divup(n, SCAN_TILE) * SCAN_TILE, span_sums, total_out_dev);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    }
     int nspans = ms3d_divup(n, SCAN_TILE);
     if (nspans > SCAN_MAX_SPANS) nspans = SCAN_MAX_SPANS;
     int span = ms3d_divup(n, nspans);
     span = ms3d_divup(span, SCAN_TILE) * SCAN_TILE;  // whole tiles per span
     nspans = ms3d_divup(n, span);
-    scan_spans_kernel<<<nspans, SCAN_THREADS, 0, stream>>>(in, out, n, span, span_sums);
+    scan_spans_kernel<<<nspans, SCAN_THREADS, 0, stream>>>(in, out, n, span, span_sums, nullptr);
     MS3D_LAUNCH_CHECK();
     scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(span_sums, nspans, total_out_dev);
     MS3D_LAUNCH_CHECK();

@@ -1,16 +1,30 @@
-"""cProfile of the host side of train steps (where the Python time goes)."""
-import sys, os, time, torch, cProfile, pstats
+"""cProfile of the host side of benchmark steps (where do the ~20 ms of Python / ctypes / torch dispatch per step go?).
+usage: python tools/host_profile.py [--model pointgroup] [--steps 10] [--top 45]"""
+import argparse, cProfile, os, pstats, sys, io
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
 import bench
-from minsu3d_amd.config import load_config
-cfg = load_config(); dev = torch.device("cuda", 0)
-model = bench.build(cfg, dev); opt = model.configure_optimizers()
-batches = [bench.make_batch([4 * i + j for j in range(4)], dev) for i in range(4)]
-for i in range(5): bench.train_step(model, model, opt, batches[i % 4])
-torch.cuda.synchronize()
-pr = cProfile.Profile()
-pr.enable()
-for i in range(10): bench.train_step(model, model, opt, batches[i % 4])
-torch.cuda.synchronize()
-pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="pointgroup"); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--top", type=int, default=45)
+ap.add_argument("--sort", default="tottime")
+args = ap.parse_args()
+prof = cProfile.Profile()
+real_time = bench.time.perf_counter
+state = {"on": False, "steps": 0}
+# profile only the timed region: bench.main() is reused, the profiler is switched on by the first timed step's barrier
+orig_sync = torch.cuda.synchronize
+
+
+def sync(*a, **k):
+    r = orig_sync(*a, **k)
+    return r
+
+
+argv = ["--model", args.model, "--steps", str(args.steps), "--warmup", "4", "--no-cpu-baseline", "--no-roofline"]
+prof.enable()
+bench.main(argv)
+prof.disable()
+s = io.StringIO()
+pstats.Stats(prof, stream=s).sort_stats(args.sort).print_stats(args.top)
+print(s.getvalue()[:12000])
