@@ -3116,7 +3116,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
         // waves split the output columns (NW waves x NBW blocks of 16), a workgroup takes KG offsets
         // (KG offsets per workgroup, waves, 16-column blocks per wave): the largest tiles that stay inside 256 registers at
         // two workgroups per CU -- every larger one tried spills (profiles/r03_fwd_experiments.txt section 6)
-        rc = nb == 3 ? launch_wgrad_bf3<14, 3, 1>(q, nblk, stream) : nb == 4 ? launch_wgrad_bf3<14, 4, 1>(q, nblk, stream)
+        rc = nb == 3 ? launch_wgrad_bf3<14, 3, 1>(q, nblk, stream) : nb == 4 ? launch_wgrad_bf3<9, 4, 1>(q, nblk, stream)
            : nb <= 6 ? launch_wgrad_bf3<9, 3, 2>(q, nblk, stream) : launch_wgrad_bf3<9, 4, 2>(q, nblk, stream);
         if (rc) return rc;
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
