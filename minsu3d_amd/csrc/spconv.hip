@@ -249,10 +249,6 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const float v = (c < d.Cin && j < d.Cout) ? d.W[((size_t)k * d.Cin + c) * d.Cout + j] : 0.f;
         d.wf[o] = v;
         if (d.stream == 1) d.wf[total + stream_slot(o, NB)] = v;
-        if (d.stream == 2 && c < d.Cin && j < d.Cout) {
-            write_bf3(d.wf + total, k, c, j, d.Cin, NB, v);
-            if ((d.Cin & 16) && c >= d.Cin - 16) write_bf3(d.wf + total, k, c + 16, j, d.Cin, NB, 0.f);           // zero pad
-        }
     }
     {
         long r = o >> 6;
@@ -264,10 +260,36 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepDesc 
         const float v = (c < d.Cout && j < d.Cin) ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : 0.f;
         d.wft[o] = v;
         if (d.stream == 1) d.wft[total + stream_slot(o, NCH)] = v;
-        if (d.stream == 2 && c < d.Cout && j < d.Cin) {
-            write_bf3(d.wft + total, k, c, j, d.Cout, NCH, v);
-            if ((d.Cout & 16) && c >= d.Cout - 16) write_bf3(d.wft + total, k, c + 16, j, d.Cout, NCH, 0.f);       // zero pad
-        }
+    }
+    if (d.stream == 2) {
+        // The three-piece bf16 images (layout: write_bf3), 16 bytes per piece and thread: thread (k, c32, nb, lane) reads the
+        // 8 weights of its operand register (input channels 32 c32 + 8 (lane >> 4) + e, column 16 nb + (lane & 15)) and
+        // stores three whole operands.  (One weight per thread scattered 2-byte stores over the image: 0.4 ms per HAIS
+        // step.)  Channels past Cin are the zero padding of a half-filled 32-channel chunk.
+        auto image = [&](float *aux, int Ci, int Co, int nb_tot, bool transposed) {
+            const int NC32 = (Ci + 31) >> 5;
+            if (o >= (long)d.K * NC32 * nb_tot * 64) return;
+            const int g = lane >> 4;
+            long r = o >> 6;
+            const int nb = (int)(r % nb_tot); r /= nb_tot;
+            const int c32 = (int)(r % NC32), k = (int)(r / NC32);
+            const int ks = (transposed && d.mirror_bwd) ? (d.K - 1 - k) : k;
+            const int j = 16 * nb + jl;
+            bf16x8 p0, p1, p2;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int c = 32 * c32 + 8 * g + e;
+                float v = 0.f;
+                if (c < Ci && j < Co) v = transposed ? d.W[((size_t)ks * d.Cin + j) * d.Cout + c] : d.W[((size_t)ks * d.Cin + c) * d.Cout + j];
+                __bf16 h0, h1, h2;
+                split3(v, h0, h1, h2);
+                p0[e] = h0; p1[e] = h1; p2[e] = h2;
+            }
+            bf16x8 *dst = reinterpret_cast<bf16x8 *>(aux) + ((((size_t)k * NC32 + c32) * nb_tot + nb) * 3) * 64 + lane;
+            dst[0] = p0; dst[64] = p1; dst[128] = p2;
+        };
+        image(d.wf + total, d.Cin, d.Cout, NB, false);
+        image(d.wft + total, d.Cout, d.Cin, NCH, true);     // the transposed operator: input side = Cout, columns = Cin
     }
 }
 
