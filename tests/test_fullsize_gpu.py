@@ -472,6 +472,15 @@ def test_bf16x3_wide_layers_are_float32_grade(be, cin, cout, level):
     e_split, e_f32 = ((y.double() - want).abs().max() / ref).item(), ((y32.double() - want).abs().max() / ref).item()
     print(f"{cin}->{cout} rows={V}: forward vs fp64  bf16x3 {e_split:.2e}  f32 MFMA {e_f32:.2e}")
     assert e_split <= 3e-6 and e_split <= 1.5 * e_f32 + 2e-7
+    # the same launch with a residual and the output statistics riding in the epilogue (what every BatchNorm-followed layer
+    # of the U-Net runs; at level 3 that is the three-tiles-per-block kernel with a ragged last block)
+    res = torch.randn(V, cout, device=dev, generator=g)
+    y2, partial, _ = be.conv_layer_forward(x, None, nbr, V, K, cin, cout, True, (scale, shift), True, res, None, True, wf_ready=wf_buf)
+    want2 = want + res.double()
+    assert ((y2.double() - want2).abs().max() / want2.abs().max()).item() <= 3e-6
+    st = partial.double().sum(0)
+    assert torch.allclose(st[0], want2.sum(0), rtol=1e-5, atol=1e-5 * want2.abs().sum(0).max().item())
+    assert torch.allclose(st[1], (want2 * want2).sum(0), rtol=1e-5)
     # backward-data: dx = conv^T(dy) masked by the fused BatchNorm + ReLU of the forward pass, then the BatchNorm chain
     dy = torch.randn(V, cout, device=dev, generator=g)
     mean, invstd = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
