@@ -3133,6 +3133,18 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
         WgradBf3Args q;
         q.xs = xs; q.dout_img = img; q.nbr = nbr; q.partial = partial_ws; q.Vout = Vout; q.K = K; q.Cin = Cin; q.Cout = Cout;
         q.NBtot = nb;
+        // Row chunks: two workgroups fit a CU (512 slots).  As many chunks as make the grid two whole rounds of them --
+        // every slab is |dW| floats written and read again by the reduction (128 chunks of 128 -> 128: 450 MB, a third
+        // of the launch), while a grid of 1.1 or 1.5 rounds idles half the chip in its last one.  Measured, us per launch
+        // with 128 / 64 / 32 chunks: 128 -> 128 at 50k rows 367 / 327 / 282, 96 -> 96 at 196k rows 776 / 854 / 1075.
+        {
+            const int kg = nb <= 4 ? (nb == 3 ? 14 : 9) : 9;
+            const int yz = ms3d_divup(K, kg) * ms3d_divup(Cin, 16);
+            static const int rounds = [] { const char *e = getenv("MS3D_WGRAD_BF3_ROUNDS"); return e ? atoi(e) : 2; }();
+            int c = (512 * rounds) / yz;
+            if (c < 8) c = 8;
+            if (c < chunks) chunks = c;
+        }
         q.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 32) * 32;
         nblk = ms3d_divup(Vout, q.rows_per_block);
         // waves split the output columns (NW waves x NBW blocks of 16), a workgroup takes KG offsets
