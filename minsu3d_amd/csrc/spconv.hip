@@ -3101,6 +3101,19 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
         p.rows_per_block = shift;  // the list kernel reads this field as the merge shift
         nblk = MS3D_PL_PARTS >> shift;
     } else {
+        if (!wgrad_bf3_ok(Vout, K, Cin, Cout, false)) {
+            // the f32 table walk: no more row chunks than fill the chip once (every chunk costs a slab of |dW|; measured:
+            // 64 -> 96, K = 8, 50k rows 103 -> 86 us, 160 -> 160 at 2.5k rows 76 -> 69; everything else has fewer anyway)
+            static const int rounds = [] { const char *e = getenv("MS3D_WGRAD_F32_ROUNDS"); return e ? atoi(e) : 1; }();
+            const int nbq = p.NBtot;
+            const int kg = nbq <= 3 ? (K >= 27 ? 9 : 8) : nbq <= 7 ? 4 : nbq == 8 ? 3 : 2;
+            const int yz = ms3d_divup(K, kg) * ms3d_divup(Cin, 16);
+            if (rounds > 0) {
+                int c = (1024 * rounds) / yz;
+                if (c < 4) c = 4;
+                if (c < chunks) chunks = c;
+            }
+        }
         p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
         nblk = ms3d_divup(Vout, p.rows_per_block);
     }
