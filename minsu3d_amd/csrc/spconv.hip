@@ -3094,6 +3094,11 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
     int nblk;
+    // offset-list kernel at 48 / 64 input channels: 64 parts x 3-4 input chunks is one workgroup per CU, and half the slabs
+    // (us per launch with 256 / 128 / 64 / 32 parts: 64 -> 64 at 196k rows 396 / 343 / 320 / 589, at 50k 143 / 141 / 122 /
+    // 193, 48 -> 48 at 196k 232 / 231 / 215 / 394; the narrow layers want all 256: 32 -> 32 at 417k 124 / 190 / 321)
+    static const int list_wide_chunks = [] { const char *e = getenv("MS3D_WGRAD_LIST_WIDE_CHUNKS"); return e ? atoi(e) : 64; }();
+    if (use_list && ms3d_divup(Cin, 16) >= 3 && chunks > list_wide_chunks) chunks = list_wide_chunks;
     if (use_list) {
         // workgroups = the list's MS3D_PL_PARTS equal-pair-count parts, merged in pairs until there are <= chunks
         int shift = 0;
