@@ -55,3 +55,23 @@ err = ((yl2.double() - yref.double()).abs().max() / yref.double().abs().max()).i
 alg = pairs * (cin + cout) * 4 + pairs * 8 + K * cin * cout * 4
 print(f"cin={cin} cout={cout} K={K} vin={vin} vout={vout} pairs/row={pairs / vout:.2f}  fwd {us:.1f} us  {alg / us / 1e3:.0f} GB/s algorithmic | layer fwd {us_l:.1f} us (aux kind {be.lib.ms3d_spconv_aux_kind(K, cin, cout)}, vs f32 kernel {err:.1e}) | wgrad {us_w:.1f} us"
       f"  env={ {k: v for k, v in os.environ.items() if k.startswith('MS3D_')} }")
+# the layer's backward entry point (backward-data with the fused BatchNorm-backward epilogue + its reduction chain +
+# backward-weight): what the modules call; minus the stand-alone backward-weight time = the backward-data side
+if K == 27:
+    mean, invstd = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
+    bn = dict(scale=scale, shift=shift, mean=mean, invstd=invstd, relu=True, training=True)
+    for _ in range(3):
+        be.conv_layer_backward(x, g, wfb, nbr, nbr, vin, vout, K, cin, cout, bn, True)
+    e0.record()
+    for _ in range(n):
+        be.conv_layer_backward(x, g, wfb, nbr, nbr, vin, vout, K, cin, cout, bn, True)
+    e1.record(); torch.cuda.synchronize()
+    us_b = e0.elapsed_time(e1) / n * 1e3
+    for _ in range(3):
+        be.conv_backward_weight(x, g, nbr, vout, K, cin, cout, pre=(scale, shift), pre_relu=True)
+    e0.record()
+    for _ in range(n):
+        be.conv_backward_weight(x, g, nbr, vout, K, cin, cout, pre=(scale, shift), pre_relu=True)
+    e1.record(); torch.cuda.synchronize()
+    us_w2 = e0.elapsed_time(e1) / n * 1e3
+    print(f"layer bwd {us_b:.1f} us = backward-weight (with prologue) {us_w2:.1f} + backward-data side {us_b - us_w2:.1f}")
