@@ -298,12 +298,13 @@ constexpr int OG = 9;  // offsets processed together: 9 neighbour indices, then 
 
 // table entries of offsets [g0, g0+OG) for one row; OR-mask instead of a select: a select lets the compiler sink
 // the load into a branch + vmcnt(0)
-__device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0, int k_hi, int (&idx)[OG])
+template <int GSZ>
+__device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0, int k_hi, int (&idx)[GSZ])
 {
     const bool row_ok = row >= 0 && row < p.Vout;
     const int safe_row = row_ok ? row : 0;
 #pragma unroll
-    for (int u = 0; u < OG; u++) {
+    for (int u = 0; u < GSZ; u++) {
         const int k = min(g0 + u, k_hi - 1);
         const int v = p.nbr[(size_t)k * p.Vout + safe_row];
         idx[u] = v | ((row_ok && g0 + u < k_hi) ? 0 : -1);
@@ -315,24 +316,26 @@ __device__ __forceinline__ void load_indices(const ConvArgs &p, int row, int g0,
 // conv -- the extra live registers cost more than the saved round trip; each group loads its own indices.)
 // Row loads are UNCONDITIONAL (index clamped to row 0, value zeroed afterwards): a branch around a gather makes the
 // compiler drain vmcnt(0) before each one, which serialises the whole neighbourhood (measured: 27 x latency).
-template <int NBT, bool ALIGNED, bool DIRECT = false>
+// GSZ: offsets per gather group -- OG where the registers allow it; the LDS table walk of 5+ column blocks (128 registers
+// at 1024 threads) takes 7 / 6, which keeps its offset loop out of scratch
+template <int NBT, bool ALIGNED, bool DIRECT = false, int GSZ = ((DIRECT || NBT < 5) ? OG : (NBT < 7 ? 7 : 6))>
 __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const float *__restrict__ sW, int k_lo, int k_hi,
                                                    int kw0, int my_row, int q, int nb0, f32x4 (&acc)[NBT])
 {
     const int l = lane_id();
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
-    for (int g0 = k_lo; g0 < k_hi; g0 += OG) {
-        int idx[OG];
+    for (int g0 = k_lo; g0 < k_hi; g0 += GSZ) {
+        int idx[GSZ];
         load_indices(p, my_row, g0, k_hi, idx);
-        bool any[OG];
+        bool any[GSZ];
 #pragma unroll
-        for (int u = 0; u < OG; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
+        for (int u = 0; u < GSZ; u++) any[u] = __ballot(idx[u] >= 0) != 0ull;
         // rows (and the fused BN scale/shift) of one 16-channel chunk
-        auto fetch = [&](int ch, f32x4 (&a)[OG], f32x4 &sc, f32x4 &sh) {
+        auto fetch = [&](int ch, f32x4 (&a)[GSZ], f32x4 &sc, f32x4 &sh) {
             const int c0 = 16 * ch + 4 * q;
 #pragma unroll
-            for (int u = 0; u < OG; u++) {
+            for (int u = 0; u < GSZ; u++) {
                 const float *row = p.in + (size_t)max(idx[u], 0) * p.Cin + c0;
                 if (ALIGNED) {
                     a[u] = *reinterpret_cast<const f32x4 *>(row);
@@ -356,13 +359,13 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
         };
         // small levels (DIRECT): the next chunk's rows travel while this chunk is multiplied (one exposed round trip
         // per chunk otherwise, 4..14 chunks per launch); `opaque0` keeps the compiler from folding the prefetch back
-        f32x4 a_next[OG], sc_next = {0.f, 0.f, 0.f, 0.f}, sh_next = sc_next;
+        f32x4 a_next[GSZ], sc_next = {0.f, 0.f, 0.f, 0.f}, sh_next = sc_next;
         if (DIRECT) fetch(0, a_next, sc_next, sh_next);
         for (int ch = 0; ch < p.NCH; ch++) {
-            f32x4 a[OG], s = {0.f, 0.f, 0.f, 0.f}, b = s;
+            f32x4 a[GSZ], s = {0.f, 0.f, 0.f, 0.f}, b = s;
             if (DIRECT) {
 #pragma unroll
-                for (int u = 0; u < OG; u++) a[u] = a_next[u];
+                for (int u = 0; u < GSZ; u++) a[u] = a_next[u];
                 s = sc_next;
                 b = sh_next;
                 if (ch + 1 < p.NCH) fetch(ch + 1 + opaque0, a_next, sc_next, sh_next);
@@ -371,7 +374,7 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
             }
             if (p.pre_scale) {
 #pragma unroll
-                for (int u = 0; u < OG; u++)
+                for (int u = 0; u < GSZ; u++)
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const float v = fmaf(a[u][t], s[t], b[t]);
@@ -379,7 +382,7 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                     }
             }
 #pragma unroll
-            for (int u = 0; u < OG; u++) {
+            for (int u = 0; u < GSZ; u++) {
                 const int keep = ~(idx[u] >> 31);  // absent neighbour (idx < 0) contributes nothing
 #pragma unroll
                 for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
@@ -390,9 +393,9 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 // the branch and wait on the spot (one L2 round trip per offset, 63 in a row on a 112-channel level).
                 // The fragments of UB offsets are requested together (explicit register arrays: left alone the
                 // scheduler keeps ~9 loads in flight, and a tiny level is exactly this chain of round trips).
-                constexpr int UB = NBT <= 2 ? OG : (NBT <= 4 ? 3 : 1);
+                constexpr int UB = NBT <= 2 ? GSZ : (NBT <= 4 ? 3 : 1);
 #pragma unroll
-                for (int u0 = 0; u0 < OG; u0 += UB) {
+                for (int u0 = 0; u0 < GSZ; u0 += UB) {
                     float wreg[UB][4][NBT];
 #pragma unroll
                     for (int uu = 0; uu < UB; uu++) {
@@ -414,7 +417,7 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < OG; u++) {
+                for (int u = 0; u < GSZ; u++) {
                     if (!any[u]) continue;
                     // LDS image holds only this block's NBT column blocks: [offset][ch][t][nb][lane]
                     const float *w = sW + (size_t)(((kw0 + (g0 - k_lo) + u) * p.NCH + ch) * 4) * NBT * 64 + l;
@@ -473,7 +476,10 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
     }
 }
 
-template <int NBT, bool ALIGNED>
+// RES: the whole image is LDS resident (persistent waves walk tiles) / streamed in groups of G offsets (one tile per wave).
+// Two kernels, not one branch: with both paths in one body the epilogue's address arithmetic, hoisted out of the
+// resident path's tile loop, went to scratch in BOTH (80-390 bytes per lane, profiles/r03_kernel_resources.txt).
+template <int NBT, bool ALIGNED, bool RES>
 __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
 {
     extern __shared__ float lds[];
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (nblk % 8 != 0) vb = blockIdx.x;  // only remap when it is a bijection
 
-    if (p.G >= p.K) {
+    if constexpr (RES) {
         // all weights resident: persistent waves walk a contiguous range of tiles
         stage(0, p.K);
         __syncthreads();
@@ -518,7 +524,12 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
-            store_tile<NBT>(p, row0, nb0, acc, s_part);
+            // a per-tile view of the arguments: the epilogue's per-column address arithmetic is loop invariant, and hoisted
+            // out of this loop it stayed live across the offset loop -- in scratch (up to 390 bytes per lane)
+            ConvArgs pt = p;
+            asm volatile("" : "+s"(pt.out), "+s"(pt.residual), "+s"(pt.bias), "+s"(pt.bn_x), "+s"(pt.bn_scale), "+s"(pt.bn_shift),
+                         "+s"(pt.bn_mean), "+s"(pt.bn_invstd));
+            store_tile<NBT>(pt, row0, nb0, acc, s_part);
         }
     } else {
         // weights streamed through LDS in groups of G offsets; one tile per wave, accumulators stay in registers
@@ -1081,15 +1092,18 @@ int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool align
 {
     // the dynamic-LDS ceiling of a kernel is raised ONCE, to the most any launch may ask for (per launch it would be a
     // race between host threads that use different sizes)
-    if (aligned) {
-        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_kernel<NBT, true>);
-        MS3D_CHECK(attr);
-        spconv_fwd_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
-    } else {
-        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_kernel<NBT, false>);
-        MS3D_CHECK(attr);
-        spconv_fwd_kernel<NBT, false><<<grid, threads, lds, stream>>>(p);
-    }
+    const bool res = p.G >= p.K;
+#define MS3D_FWD_LAUNCH(A, R)                                                                                        \
+    do {                                                                                                             \
+        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_kernel<NBT, A, R>);                \
+        MS3D_CHECK(attr);                                                                                            \
+        spconv_fwd_kernel<NBT, A, R><<<grid, threads, lds, stream>>>(p);                                             \
+    } while (0)
+    if (aligned && res) MS3D_FWD_LAUNCH(true, true);
+    else if (aligned) MS3D_FWD_LAUNCH(true, false);
+    else if (res) MS3D_FWD_LAUNCH(false, true);
+    else MS3D_FWD_LAUNCH(false, false);
+#undef MS3D_FWD_LAUNCH
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1113,6 +1127,7 @@ __host__ __device__ constexpr size_t pairlist_wave_floats(int nbt) { return (siz
 template <int NBT, int NCH>
 __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
 {
+    struct { const float *bias, *bn_scale, *bn_shift, *bn_mean, *bn_invstd; } ep = {p.bias, p.bn_scale, p.bn_shift, p.bn_mean, p.bn_invstd};
     extern __shared__ float lds[];
     constexpr int CW = NBT * 16;  // accumulator row width
     constexpr int F4 = CW / 4;
@@ -1331,6 +1346,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         first_entries(desc, nxt);
         __builtin_amdgcn_wave_barrier();
         // ---- epilogue: CR x CW accumulator tile, row-major, 16 B per lane per step
+        // (per-tile view of the per-column operands: hoisted out of the tile loop they sat in scratch across the pair loop)
+        asm volatile("" : "+s"(ep.bias), "+s"(ep.bn_scale), "+s"(ep.bn_shift), "+s"(ep.bn_mean), "+s"(ep.bn_invstd));
 #pragma unroll
         for (int i = 0; i < F4; i++) {
             const int r = i * (64 / F4) + l / F4;
@@ -1345,19 +1362,19 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
 #pragma unroll
                     for (int t = 0; t < 4; t++) o4[t] += rs[t];
                 }
-                if (p.bias) {
+                if (ep.bias) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++) o4[t] += p.bias[col + t];
+                    for (int t = 0; t < 4; t++) o4[t] += ep.bias[col + t];
                 }
                 if (p.bn_x) {
                     const f32x4 x = *reinterpret_cast<const f32x4 *>(p.bn_x + o);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const float z = fmaf(x[t], p.bn_scale[col + t], p.bn_shift[col + t]);
+                        const float z = fmaf(x[t], ep.bn_scale[col + t], ep.bn_shift[col + t]);
                         const float g = (z > 0.f) ? o4[t] : 0.f;
                         o4[t] = g;
                         st1[t] += g;
-                        st2[t] += g * ((x[t] - p.bn_mean[col + t]) * p.bn_invstd[col + t]);
+                        st2[t] += g * ((x[t] - ep.bn_mean[col + t]) * ep.bn_invstd[col + t]);
                     }
                 } else if (p.out_stats) {
 #pragma unroll
@@ -1437,6 +1454,7 @@ __host__ __device__ constexpr size_t pairstream_wave_floats(int nbt) { return PS
 template <int NBT, int CG>
 __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
 {
+    struct { const float *bias, *bn_scale, *bn_shift, *bn_mean, *bn_invstd; } ep = {p.bias, p.bn_scale, p.bn_shift, p.bn_mean, p.bn_invstd};
     extern __shared__ float lds[];
     constexpr int CW = NBT * 16, RS = CW + PSW;  // accumulator row width / stride
     constexpr int F4 = CW / 4;                    // 16-byte chunks per row
@@ -1647,6 +1665,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
         desc = next_desc;
         __builtin_amdgcn_wave_barrier();
         // ---- epilogue: PSR x CW accumulator tile, row-major, 16 B per lane per step
+        // (per-tile view of the per-column operands: hoisted out of the tile loop they sat in scratch across the pair loop)
+        asm volatile("" : "+s"(ep.bias), "+s"(ep.bn_scale), "+s"(ep.bn_shift), "+s"(ep.bn_mean), "+s"(ep.bn_invstd));
         for (int r0 = 0; r0 < PSR; r0 += RPS) {
             const int r = r0 + l / F4;
             if (!ep_lane || r >= PSR) continue;
@@ -1661,19 +1681,19 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
 #pragma unroll
                     for (int t = 0; t < 4; t++) o4[t] += rs[t];
                 }
-                if (p.bias) {
+                if (ep.bias) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++) o4[t] += p.bias[col + t];
+                    for (int t = 0; t < 4; t++) o4[t] += ep.bias[col + t];
                 }
                 if (p.bn_x) {
                     const f32x4 x = *reinterpret_cast<const f32x4 *>(p.bn_x + o);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const float z = fmaf(x[t], p.bn_scale[col + t], p.bn_shift[col + t]);
+                        const float z = fmaf(x[t], ep.bn_scale[col + t], ep.bn_shift[col + t]);
                         const float gz = (z > 0.f) ? o4[t] : 0.f;
                         o4[t] = gz;
                         st1[t] += gz;
-                        st2[t] += gz * ((x[t] - p.bn_mean[col + t]) * p.bn_invstd[col + t]);
+                        st2[t] += gz * ((x[t] - ep.bn_mean[col + t]) * ep.bn_invstd[col + t]);
                     }
                 } else if (p.out_stats) {
 #pragma unroll
