@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int TILE_ROWS = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_C_STAGE = 64;  // channels staged per pass
 
