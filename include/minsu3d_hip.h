@@ -296,7 +296,10 @@ float ms3d_event_elapsed_ms(void *start, void *stop);
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
-                               int need_dx, float *dx, float *dgb, float *dW, float *ws,
+                               int need_dx, float *dx,
+                               const float *dx_add /* or NULL: [Vin, Cin] added to dx -- the gradient that reaches x over a skip
+                                                      connection (fused into the BatchNorm-backward pass / the residual epilogue) */,
+                               float *dgb, float *dW, float *ws,
                                const int *ol_fwd_kt_start /* offset list of nbr_fwd or NULL */, const int *ol_fwd_entries,
                                const int *pl_bwd_tile_start /* pair list of nbr_bwd or NULL */, const int *pl_bwd_entries,
                                void *ev_start /* hipEvent_t or NULL: around the backward-data kernel */, void *ev_stop,
@@ -317,6 +320,9 @@ int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float
 int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream);
 int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
                       const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream);
+/* the same with `add` [V, C] (or NULL) added to the result */
+int ms3d_bn_bwd_apply_add(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
+                          const float *invstd, const float *s1s2, const float *add, float *dx, ms3d_stream_t stream);
 int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const float *scale, const float *shift,
                         const float *mean, const float *invstd, int relu, float *dz, float *partial_ws,
                         int partial_rows, int *nparts_out /*[host]*/, ms3d_stream_t stream);

@@ -11,3 +11,4 @@ from .tensor import SparseTensor, CoordinateManager, cat, prefetch_coordinates  
 from .modules import (MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,  # noqa: F401
                       MinkowskiReLU, prepare_conv_weights, release_conv_weights)
 from .functional import gather_rows  # noqa: F401  (engine extra: x[idx] with a scatter-add backward)
+from .functional import SkipLink  # noqa: F401  (engine extra: a residual block's skip gradient, see functional.py)

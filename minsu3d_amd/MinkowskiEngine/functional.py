@@ -19,12 +19,25 @@ class ConvSpec:
         self.K, self.cin, self.cout, self.mirror = K, cin, cout, mirror
 
 
+class SkipLink:
+    """The gradient of a residual connection, handed from the LAST convolution of the block (whose epilogue added the
+    skip) to the FIRST one (whose input is the skipped tensor): `out = x + branch(x)` sends dy to x twice -- through the
+    branch and directly -- and autograd would add the two with an elementwise kernel per block and step.  The tail keeps
+    its dy here instead of returning it for `residual`; the head's backward-data pass adds it to dx inside the
+    BatchNorm-backward kernel it runs anyway (same two operands, same sum)."""
+    __slots__ = ("grad", "armed")
+
+    def __init__(self):
+        self.grad = None
+        self.armed = False     # set by the head's forward: only then may the tail keep its dy back
+
+
 class SparseConvFn(torch.autograd.Function):
     """(y, stats) = conv(act(x)) [+ residual];  stats = per-block (sum, sum of squares) of y from the kernel epilogue
     (non-differentiable side output that lets the next BatchNorm skip its statistics pass)"""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, residual, spec, bn, want_stats):
+    def forward(ctx, x, W, gamma, beta, residual, spec, bn, want_stats, skip=None):
         be = get_backend()
         pre = (bn["scale"], bn["shift"]) if bn is not None else None
         # weight images laid out for the whole model in one launch at the start of its forward (modules.prepare_conv_weights):
@@ -37,6 +50,12 @@ class SparseConvFn(torch.autograd.Function):
         if stats is None:
             stats = x.new_zeros(0)
         ctx.spec, ctx.bn, ctx.wf_buf, ctx.has_res = spec, bn, wf_buf, residual is not None
+        if skip is not None:     # None | ("head", SkipLink) | ("tail", SkipLink)
+            if skip[0] == "head":
+                skip[1].armed = True
+            elif not (skip[1].armed and residual is not None):
+                skip = None      # no head took the link: the skip gradient goes the ordinary way
+        ctx.skip = skip
         ctx.save_for_backward(x, W)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)
@@ -48,6 +67,10 @@ class SparseConvFn(torch.autograd.Function):
         spec, bn = ctx.spec, ctx.bn
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
+        role, link = ctx.skip if ctx.skip is not None else (None, None)
+        add = None
+        if role == "head":
+            add, link.grad = link.grad, None
         if bn is not None and not bn["relu"]:
             # BatchNorm without ReLU in front of a convolution (not used by the reference): unfused path
             wft = be.prep_weights(W.view(spec.K, spec.cin, spec.cout), spec.K, spec.cout, spec.cin, transpose=True,
@@ -58,11 +81,20 @@ class SparseConvFn(torch.autograd.Function):
             dW = be.conv_backward_weight(x, dy, spec.nbr_fwd, spec.vout, spec.K, spec.cin, spec.cout,
                                          pre=(bn["scale"], bn["shift"]), pre_relu=False)
         else:
+            fused = add is not None and ctx.needs_input_grad[0] and be.fuses_dx_add(bn)
             dx, dgb, dW = be.conv_layer_backward(x, dy, ctx.wf_buf, spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout,
-                                                 spec.K, spec.cin, spec.cout, bn, ctx.needs_input_grad[0])
+                                                 spec.K, spec.cin, spec.cout, bn, ctx.needs_input_grad[0],
+                                                 **({"dx_add": add} if fused else {}))
+            if fused:
+                add = None
+        if add is not None and dx is not None:
+            dx = dx + add
         dgamma = dgb[1] if dgb is not None else None
         dbeta = dgb[0] if dgb is not None else None
-        return dx, dW.view_as(W), dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
+        d_res = dy if ctx.has_res else None
+        if role == "tail" and ctx.has_res:
+            link.grad, d_res = dy, None      # the head adds it to its dx
+        return dx, dW.view_as(W), dgamma, dbeta, d_res, None, None, None, None
 
 
 class BNActFn(torch.autograd.Function):
@@ -88,14 +120,16 @@ def bn_act(x, pending):
     return BNActFn.apply(x, pending["gamma"], pending["beta"], pending)
 
 
-def conv(x, W, spec, pending, residual=None, want_stats=False):
-    """-> (features, stats or None)"""
+def conv(x, W, spec, pending, residual=None, want_stats=False, skip=None):
+    """-> (features, stats or None).  skip: ("head" | "tail", SkipLink) of a residual block, see SkipLink"""
     if pending is not None and pending.get("gamma") is None:
         x, pending = torch.relu(x), None
+        if skip is not None and skip[0] == "head":
+            skip = None       # x is no longer the skipped tensor itself: leave that block to autograd
     if pending is None:
-        y, st = SparseConvFn.apply(x, W, None, None, residual, spec, None, want_stats)
+        y, st = SparseConvFn.apply(x, W, None, None, residual, spec, None, want_stats, skip)
     else:
-        y, st = SparseConvFn.apply(x, W, pending["gamma"], pending["beta"], residual, spec, pending, want_stats)
+        y, st = SparseConvFn.apply(x, W, pending["gamma"], pending["beta"], residual, spec, pending, want_stats, skip)
     return y, (st if want_stats else None)
 
 

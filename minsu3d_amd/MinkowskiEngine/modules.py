@@ -69,9 +69,10 @@ def release_conv_weights():
 class MinkowskiConvolution(_ConvBase):
     """k3 s1 (submanifold, output coords = input coords), k2 s2 (downsample) and k1 s1"""
 
-    def forward(self, x: SparseTensor, residual: SparseTensor = None):
+    def forward(self, x: SparseTensor, residual: SparseTensor = None, skip=None):
         """`residual` (same coordinate map as the output) is added in the kernel epilogue -- used by ResidualBlock
-        instead of a separate `+=` pass; not part of ME's API."""
+        instead of a separate `+=` pass; `skip` = ("head" | "tail", functional.SkipLink) routes the skip connection's
+        gradient through the block's first convolution instead of an elementwise add.  Neither is part of ME's API."""
         cm, ts = x.coordinate_manager, x.tensor_stride
         cin, cout = self.in_channels, self.out_channels
         if self.kernel_size == 3 and self.stride == 1:
@@ -99,8 +100,10 @@ class MinkowskiConvolution(_ConvBase):
             feats = torch.nn.functional.pad(feats, (0, pad))
             kernel = torch.nn.functional.pad(kernel, (0, 0, 0, pad))
             spec = Fn.ConvSpec(spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout, spec.K, 16, cout, spec.mirror)
+        if skip is not None and feats is not x._F:
+            skip = None            # (padded input rows: not the skipped tensor any more)
         y, stats = Fn.conv(feats, kernel, spec, pending,
-                           residual=None if residual is None else residual._raw(), want_stats=self.training)
+                           residual=None if residual is None else residual._raw(), want_stats=self.training, skip=skip)
         return x._like(y, tensor_stride=out_ts, stats=stats)
 
 

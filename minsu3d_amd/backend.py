@@ -379,7 +379,7 @@ def _p(t):
 _VP, _I = C.c_void_p, C.c_int
 _FAST_ARGTYPES = {
     "ms3d_spconv_layer_forward": [_VP] * 3 + [_I] * 5 + [_VP] * 2 + [_I] + [_VP] * 5 + [_VP] * 2 + [_VP] * 2 + [_VP],
-    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 4 + [_VP] * 4 + [_VP] * 4 +
+    "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 5 + [_VP] * 4 + [_VP] * 4 +
                                   [_VP, _VP, _I, _VP],
     "ms3d_bn_finalize": [_VP, _I, C.c_long, _I, C.c_float, C.c_float] + [_VP] * 4 + [_VP] * 4 + [_VP],
 }
@@ -743,8 +743,10 @@ class _HipEngine:
             ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")
         return y, stats, wf_buf
 
-    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx):
-        """-> (dx or None, dgb [2,cin] = (dbeta, dgamma) or None, dW [K,cin,cout])"""
+    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None):
+        """-> (dx or None, dgb [2,cin] = (dbeta, dgamma) or None, dW [K,cin,cout]).  dx_add [vin, cin]: a gradient that
+        reaches x over a skip connection, added to dx inside the BatchNorm-backward pass / the residual epilogue (needs
+        training-mode statistics when a BatchNorm is fused: `fuses_dx_add`)"""
         x = self._dev(x); dy = self._dev(dy)
         dev = x.device
         ws = self.ws.get("layer", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
@@ -769,7 +771,7 @@ class _HipEngine:
             int(cin), int(cout), _p(bn["scale"] if has_bn else None), _p(bn["shift"] if has_bn else None),
             _p(bn["mean"] if has_bn else None), _p(bn["invstd"] if has_bn else None),
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
-            _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
+            _p(_f32(dx_add) if (dx_add is not None and need_dx) else None), _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
             _p(plb[1]), ev0, ev1, ev2, ev3, _p(ws2), side.cuda_stream if side is not None else None,
             int(mode == 1), _lib.stream_handle()), "ms3d_spconv_layer_backward")
         if mode == 2:
@@ -778,6 +780,11 @@ class _HipEngine:
             x.record_stream(side); dy.record_stream(side); dW.record_stream(side)
             self._queue_wgrad_join(side)
         return (dx if need_dx else None), dgb, dW
+
+    @staticmethod
+    def fuses_dx_add(bn):
+        """can conv_layer_backward add a skip gradient itself for this fused BatchNorm description?"""
+        return bn is None or (bool(bn["relu"]) and bool(bn["training"]))
 
     def wgrad_stream_mode(self):
         """MS3D_WGRAD_STREAM: 0 (default) backward-weight on the caller's stream; 1: on a second stream, joined at the

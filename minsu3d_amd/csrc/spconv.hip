@@ -2495,6 +2495,7 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, long n, int C, cons
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *__restrict__ x, long n, int C, long V,
                                     const float *__restrict__ scale, const float *__restrict__ mean,
                                     const float *__restrict__ invstd, const float *__restrict__ s1s2,
+                                    const float *__restrict__ add /* or null: a gradient arriving over a skip connection */,
                                     float *__restrict__ dx)
 {
     const float invV = 1.f / (float)V;
@@ -2513,6 +2514,10 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *_
             o.y = sc.y * (g.y - a1.y * invV - ((xv.y - mu.y) * is.y) * a2.y * invV);
             o.z = sc.z * (g.z - a1.z * invV - ((xv.z - mu.z) * is.z) * a2.z * invV);
             o.w = sc.w * (g.w - a1.w * invV - ((xv.w - mu.w) * is.w) * a2.w * invV);
+            if (add) {
+                const float4 r = reinterpret_cast<const float4 *>(add)[v];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
             reinterpret_cast<float4 *>(dx)[v] = o;
         }
         return;
@@ -2520,7 +2525,8 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *_
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         const float xh = (x[e] - mean[c]) * invstd[c];
-        dx[e] = scale[c] * (dz[e] - s1s2[c] * invV - xh * s1s2[C + c] * invV);
+        const float o = scale[c] * (dz[e] - s1s2[c] * invV - xh * s1s2[C + c] * invV);
+        dx[e] = add ? o + add[e] : o;
     }
 }
 
@@ -3264,16 +3270,21 @@ int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms
     return 0;
 }
 
-int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
-                      const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream)
+int ms3d_bn_bwd_apply_add(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
+                          const float *invstd, const float *s1s2, const float *add, float *dx, ms3d_stream_t stream)
 {
     const long n = V * C;
     if (n <= 0) return 0;
     const long work = (C & 3) == 0 ? n / 4 : n;
     bn_bwd_apply_kernel<<<(int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192), 256, 0, (hipStream_t)stream>>>(
-        dz, x, n, C, V, scale, mean, invstd, s1s2, dx);
+        dz, x, n, C, V, scale, mean, invstd, s1s2, add, dx);
     MS3D_LAUNCH_CHECK();
     return 0;
+}
+int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
+                      const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream)
+{
+    return ms3d_bn_bwd_apply_add(dz, x, V, C, scale, mean, invstd, s1s2, nullptr, dx, stream);
 }
 
 int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const float *scale, const float *shift,
@@ -3372,10 +3383,10 @@ static hipEvent_t order_event()
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
                                const int *nbr_bwd, int Vin, int Vout, int K, int Cin, int Cout, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int pre_relu, int training,
-                               int need_dx, float *dx, float *dgb, float *dW, float *ws, const int *ol_fwd_kt_start,
-                               const int *ol_fwd_entries, const int *pl_bwd_tile_start, const int *pl_bwd_entries,
-                               void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop, float *ws_wgrad,
-                               ms3d_stream_t wgrad_stream, int join, ms3d_stream_t stream)
+                               int need_dx, float *dx, const float *dx_add, float *dgb, float *dW, float *ws,
+                               const int *ol_fwd_kt_start, const int *ol_fwd_entries, const int *pl_bwd_tile_start,
+                               const int *pl_bwd_entries, void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop,
+                               float *ws_wgrad, ms3d_stream_t wgrad_stream, int join, ms3d_stream_t stream)
 {
     const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
     const float *wft = wf_buf + 3 * nwf, *wfts = wf_buf + 4 * nwf;
@@ -3411,7 +3422,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     if (ev_start && (need_dx || bn)) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_start, main));
     if (need_dx || bn) {
         if (!bn) {
-            rc = spconv_forward_impl(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+            // dx_add (the gradient that reaches x over a skip connection) rides in the residual epilogue
+            rc = spconv_forward_impl(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, dx_add, nullptr, nullptr,
                                      nullptr, nullptr, nullptr, nullptr, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts,
                                      aux_kind, stream);
             if (rc) return rc;
@@ -3431,8 +3443,9 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             if (rc) return rc;
             if (need_dx) {
                 if (training) {
-                    rc = ms3d_bn_bwd_apply(dx, x, Vin, Cin, scale, mean, invstd, dgb, dx, stream);
+                    rc = ms3d_bn_bwd_apply_add(dx, x, Vin, Cin, scale, mean, invstd, dgb, dx_add, dx, stream);
                 } else {
+                    if (dx_add) return MS3D_E_UNSUPPORTED;   // eval-mode statistics: the caller adds the skip gradient itself
                     rc = ms3d_bn_apply(dx, Vin, Cin, scale, nullptr, 0, dx, stream);  // dx = dz * scale
                 }
                 if (rc) return rc;

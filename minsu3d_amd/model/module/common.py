@@ -5,6 +5,7 @@
 Every [BN, ReLU, conv] triple executes as ONE fused gather kernel (lazy BN/ReLU, see MinkowskiEngine/tensor.py)."""
 from collections import OrderedDict
 
+import torch
 import torch.nn as nn
 
 from ... import MinkowskiEngine as ME
@@ -34,11 +35,27 @@ class ResidualBlock(nn.Module):
         if layers is None or len(layers) != len(self.conv_branch):
             # (slicing an nn.Sequential builds a new module on every call: 32 blocks x ~20 us per step)
             layers = self.__dict__["_layers"] = tuple(self.conv_branch)
+        # identity skip: out = x + branch(x) sends the output gradient to x twice.  Instead of autograd's elementwise add per
+        # block, the last convolution hands its dy to the first one, whose BatchNorm-backward pass adds it to dx
+        # (MinkowskiEngine/functional.py, SkipLink).  Only when the skipped tensor IS the first convolution's input rows.
+        link = None
+        if (self.downsample is None and torch.is_grad_enabled() and x._pending is None
+                and isinstance(layers[-1], ME.MinkowskiConvolution)):
+            link = ME.SkipLink()
         h = x
         for layer in layers[:-1]:
+            if link is not None and not link.armed and isinstance(layer, ME.MinkowskiConvolution):
+                if h._F is not x._F:
+                    link = None          # something already touched the rows: leave the block to autograd
+                    h = layer(h)
+                else:
+                    h = layer(h, skip=("head", link))
+                continue
             h = layer(h)
         # `y = conv(h); y += skip` of the reference (common.py:43-49) as one kernel: the residual add and the batch
         # statistics the next BatchNorm needs ride in the last convolution's epilogue
+        if link is not None and link.armed:
+            return layers[-1](h, residual=skip, skip=("tail", link))
         return layers[-1](h, residual=skip)
 
 

@@ -162,7 +162,11 @@ class OracleBackend:
         y, stats = res if want_stats else (res, None)
         return y, stats, (wf, wft)
 
-    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx):
+    @staticmethod
+    def fuses_dx_add(bn):
+        return True
+
+    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None):
         wft = wf_buf[1]
         dx = dgb = None
         if bn is None:
@@ -175,6 +179,8 @@ class OracleBackend:
             if need_dx:
                 dx = (self.bn_bwd_apply(dz, x, bn["scale"], bn["mean"], bn["invstd"], dgb) if bn["training"]
                       else dz * bn["scale"])
+        if dx is not None and dx_add is not None:
+            dx = dx + dx_add        # the gradient that reaches x over a skip connection (MinkowskiEngine/functional.py)
         pre = (bn["scale"], bn["shift"]) if bn is not None else None
         dW = self.conv_backward_weight(x, dy, nbr_fwd, vout, K, cin, cout, pre=pre, pre_relu=bool(bn and bn["relu"]))
         return dx, dgb, dW
