@@ -16,6 +16,8 @@ def _bn_relu_conv(norm_fn, c_in, conv):
 
 
 class ResidualBlock(nn.Module):
+    fuse_skip_grad = True     # the skip connection's gradient through the first convolution's backward pass (see forward)
+
     def __init__(self, in_channels, out_channels, dimension=3, norm_fn=None):
         super().__init__()
         norm_fn = norm_fn or ME.MinkowskiBatchNorm
@@ -39,7 +41,7 @@ class ResidualBlock(nn.Module):
         # block, the last convolution hands its dy to the first one, whose BatchNorm-backward pass adds it to dx
         # (MinkowskiEngine/functional.py, SkipLink).  Only when the skipped tensor IS the first convolution's input rows.
         link = None
-        if (self.downsample is None and torch.is_grad_enabled() and x._pending is None
+        if (self.fuse_skip_grad and self.downsample is None and torch.is_grad_enabled() and x._pending is None
                 and isinstance(layers[-1], ME.MinkowskiConvolution)):
             link = ME.SkipLink()
         h = x

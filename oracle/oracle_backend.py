@@ -164,7 +164,8 @@ class OracleBackend:
 
     @staticmethod
     def fuses_dx_add(bn):
-        return True
+        # as HipBackend: frozen (eval-mode) statistics leave the skip gradient to the caller's fallback
+        return bn is None or (bool(bn["relu"]) and bool(bn["training"]))
 
     def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None):
         wft = wf_buf[1]

@@ -265,3 +265,48 @@ def test_batchnorm_counter_and_cumulative_momentum(cpu_backend):
     bn2(x[0]).features                      # one pending batch on the fresh instance ...
     bn2.load_state_dict(sd)                 # ... which the loaded count replaces
     assert int(bn2.state_dict()["bn.num_batches_tracked"]) == 3
+
+
+def test_skip_gradient_through_the_first_convolution_equals_autograd(cpu_backend):
+    """ResidualBlock hands the skip connection's gradient from its last convolution to its first one (SkipLink) instead
+    of letting autograd add it with an elementwise kernel: every parameter gradient of the network must come out the same
+    (the same two operands are added), with training-mode and with frozen (eval-mode) BatchNorm statistics -- the latter
+    takes the un-fused fallback inside the backward function"""
+    from minsu3d_amd.model.module.common import ResidualBlock
+    import minsu3d_amd.MinkowskiEngine.functional as Fn
+    batch = small_batch()
+
+    def grads(fuse, freeze_bn):
+        model = build_model(seed=3)
+        model.train()
+        if freeze_bn:
+            for m in model.modules():
+                if m.__class__.__name__ == "MinkowskiBatchNorm":
+                    m.eval()
+        ResidualBlock.fuse_skip_grad = fuse
+        try:
+            made = []
+            orig = Fn.SkipLink.__init__
+
+            def counting(self):
+                orig(self)
+                made.append(self)
+            Fn.SkipLink.__init__ = counting
+            try:
+                total = sum(model._loss(batch, model(batch)).values())
+                total.backward()
+            finally:
+                Fn.SkipLink.__init__ = orig
+        finally:
+            ResidualBlock.fuse_skip_grad = True
+        assert all(l.grad is None for l in made)               # every kept-back gradient was consumed
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, len(made), \
+            sum(l.armed for l in made)
+
+    for freeze_bn in (False, True):
+        fused, n_links, n_armed = grads(True, freeze_bn)
+        plain, n_off, _ = grads(False, freeze_bn)
+        assert n_links >= 8 and n_armed >= 8 and n_off == 0      # the identity blocks of backbone + ScoreNet took the link
+        assert fused.keys() == plain.keys()
+        for n in fused:
+            assert torch.allclose(fused[n], plain[n], rtol=1e-6, atol=1e-9), (n, freeze_bn)
