@@ -17,7 +17,7 @@ nM*(Cin+Cout)*4 + nM*8 + K*Cin*Cout*4 with each table's real pair count nM, divi
 and `top_kernels` lists the five largest kernel groups by time (convolutions by variant and shape, and the grouping
 operators with their SURVEY 8d byte formulas).  `traffic` (HBM bytes of the same convolution kernels per step, from
 PMC counters) needs separate rocprofv3 --pmc passes, which this script cannot run on itself: it is read from
-profiles/r03_traffic_<model>.json (made by tools/scripts/pmc_traffic.sh from FETCH_SIZE / WRITE_SIZE passes of this
+the newest profiles/rNN_traffic_<model>.json (made by tools/scripts/pmc_traffic.sh from FETCH_SIZE / WRITE_SIZE passes of this
 script; corrections as MI355X_MICROARCH.md prescribes) and is null when that file is absent or carries the digest of
 other kernel sources than the ones running (`kernel_source_digest`).  `step_ms` = median / min / max / mean of the
 per-step durations between HIP events at the step boundaries; `ms_per_step` = wall time of the timed region / steps.
@@ -78,15 +78,25 @@ def build(cfg, device, seed=0):
     return model
 
 
+PREFETCH_AT = os.environ.get("MS3D_PREFETCH_AT", "grouping")
+
+
 def train_step(model, ddp, opt, batch, next_batch=None):
     opt.zero_grad(set_to_none=True)
+    # input pipelining, as a data loader would do it: the coordinate-only work of the NEXT batch (row order, kernel maps,
+    # pair lists) is built on its own stream -- issued right behind this step's backbone, so that it runs inside the
+    # grouping window where the chip is mostly idle (MS3D_PREFETCH_AT=backward: beside the backward pass, as in round 3)
+    prefetch = None
+    if next_batch is not None:
+        def prefetch():
+            ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
+                                    channels=model.backbone.level_channels)
+        if PREFETCH_AT == "grouping":
+            model.schedule_after_backbone(prefetch)
     out = ddp(batch)
     loss = sum(model._loss(batch, out).values())
-    if next_batch is not None:
-        # input pipelining, as a data loader would do it: the coordinate-only work of the NEXT batch (row order, kernel
-        # maps, pair lists) is built on a side stream while this step's backward pass runs
-        ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
-                                channels=model.backbone.level_channels)
+    if prefetch is not None and PREFETCH_AT != "grouping":
+        prefetch()
     loss.backward()
     opt.step()
     return loss
@@ -216,8 +226,10 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     # HBM bytes of the same kernels from the PMC passes committed with this code (separate rocprofv3 --pmc FETCH_SIZE /
     # --pmc WRITE_SIZE runs of this script, tools/scripts/pmc_traffic.sh); null when the file is missing or is for
     # another model
-    tfile = os.path.join(ROOT, "profiles", f"r03_traffic_{model_name}.json")
-    if os.path.exists(tfile):
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_traffic_{model_name}.json")))
+    tfile = tfiles[-1] if tfiles else None          # the newest round's passes
+    if tfile is not None:
         with open(tfile) as fh:
             t = json.load(fh)
         if t.get("kernel_source_digest") == kernel_source_digest():
@@ -253,6 +265,24 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
     return roof, top
 
 
+def other_model_line(model_name, args):
+    """BASELINE configs 3 / 4 for the driver's one JSON line: the same benchmark for another model family, run in a CHILD
+    process after (outside) the timed headline region -- a fresh process, so nothing of it touches the headline numbers"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", model_name, "--gpus", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--batch", str(args.batch), "--no-cpu-baseline", "--also", "none"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        roof = d.get("roofline") or {}
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "step_ms_median": d["step_ms"]["median"], "workload": d["config"]["workload"],
+                "roofline_frac": roof.get("frac"), "roofline_achieved_GBs": roof.get("achieved"),
+                "conv_kernel_ms_per_step": roof.get("kernel_ms_per_step"), "traffic": roof.get("traffic")}
+    except Exception as e:      # the headline line must not be lost to a failure of an extra
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +301,11 @@ def main(argv=None):
     ap.add_argument("--all-kernels", action="store_true", help="print every timed kernel group to stderr")
     ap.add_argument("--override", action="append", default=[], help="Hydra-style key=value on top of the model's config")
     ap.add_argument("--scene", default=None, help="JSON keyword arguments of synthetic.make_scene (smaller scenes)")
+    ap.add_argument("--also", default="auto",
+                    help="comma list of the other model families (hais,softgroup) to run AFTER the timed headline region, "
+                         "each in its own child process, and report under `extra` (BASELINE configs 3 / 4: value, "
+                         "ms_per_step, roofline.frac); 'none' = off; 'auto' = hais,softgroup for the plain headline "
+                         "invocation (PointGroup, one GPU, roofline and cpu_baseline on), none otherwise")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu = DRY RUN of the launch / sharding / barrier / max-over-ranks / reporting path on host "
                          "tensors over gloo (tests/bench_dryrun.py installs the operator backend); never a measurement")
@@ -346,14 +381,21 @@ def main(argv=None):
                         "max": round(float(step_ms.max()), 3), "mean": round(float(step_ms.mean()), 3),
                         "clock": "HIP events at the step boundaries on the main stream (rank 0)"},
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "arithmetic": "f32 storage and accumulation everywhere; layers with both sides >= 48 channels multiply on exact "
+                          "3-piece bf16 splits of both operands (6 of the 9 piece products, v_mfma_f32_16x16x32_bf16, f32 "
+                          "accumulate: 1.7-2.0e-6 of the largest output vs float64, the f32 MFMA kernel's own 1.3-1.6e-6), "
+                          "all other layers on v_mfma_f32_16x16x4_f32",
+            "data": "synthetic",
             "config": {"workload": f"{cfg.model.network.module} m={cfg.model.network.m}, synthetic ScanNet-shaped scenes "
                                    f"(~{n_pts / 1000:.0f}k points, ~{n_vox / 1000:.0f}k voxels @2cm each), "
                                    f"{args.batch} scenes/GPU/step, grouping+ScoreNet branch on, fwd+loss+bwd+Adam",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "grouping_inputs": "GT labels, GT offsets + N(0,4cm) (random-init net groups nothing)",
                        "input_pipelining": "coordinate-only work of step i+1's batch (row order, kernel maps, pair lists) "
-                                           "runs on a side stream during step i's backward; every step builds its own"},
+                                           "runs on its own stream during step i's " +
+                                           ("grouping window" if PREFETCH_AT == "grouping" else "backward pass") +
+                                           "; every step builds its own"},
         }
         if timer is not None:
             timer.sampling = False
@@ -371,6 +413,13 @@ def main(argv=None):
             line["dry_run"] = "host tensors over gloo: exercises the launch path only, the numbers mean nothing"
         if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(cfg, config1=args.cpu_config1)
+        also = args.also
+        if also == "auto":
+            plain = (args.model == "pointgroup" and world == 1 and not dry and not args.no_roofline
+                     and not args.no_cpu_baseline and not args.override and not args.scene and args.density == 1700.0)
+            also = "hais,softgroup" if plain else "none"
+        if also != "none" and world == 1 and not dry:
+            line["extra"] = {m: other_model_line(m, args) for m in also.split(",") if m and m != args.model}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

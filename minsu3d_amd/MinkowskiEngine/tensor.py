@@ -94,8 +94,8 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channe
     key = (coordinates.data_ptr(), tuple(coordinates.shape))
     if key in _PREFETCHED:
         return
-    from ..backend import side_stream, worker
-    side = side_stream(coordinates.device)
+    from ..backend import prefetch_stream, prefetch_worker as worker
+    side = prefetch_stream(coordinates.device)
     if wait_current_stream:
         side.wait_stream(torch.cuda.current_stream())
 

@@ -70,6 +70,28 @@ def worker():
     return _POOL
 
 
+_PF_POOL = None
+_PF = {}
+
+
+def prefetch_worker():
+    """the helper thread of the input pipeline (MinkowskiEngine.prefetch_coordinates): its own thread and stream, because
+    PointGroup's second grouping occupies `worker()` / `side_stream()` exactly when the next batch's coordinate work is
+    meant to run -- inside the grouping window, where the chip is mostly idle"""
+    global _PF_POOL
+    if _PF_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _PF_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ms3d-prefetch")
+    return _PF_POOL
+
+
+def prefetch_stream(device):
+    s = _PF.get(device)
+    if s is None:
+        s = _PF[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def wgrad_stream(device):
     """the stream the backward-weight kernels run on beside the backward-data chain (conv_layer_backward)"""
     s = _WGRAD.get(device)

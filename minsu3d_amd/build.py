@@ -10,7 +10,18 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libminsu3d_hip.so")
 OBJ_DIR = os.path.join(HERE, "..", "build", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-FLAGS += os.environ.get("MS3D_EXTRA_HIPCC_FLAGS", "").split()     # experiment builds (knock-out variants)
+# Experiment builds (knock-out variants, tools/scripts/ko_build_run.sh): extra flags build into THEIR OWN object
+# directory and library file (suffix = a digest of the flags), so that the product library and its objects are never
+# overwritten by a variant and a later plain build() cannot pick a variant's objects up; the returned path
+# goes into MS3D_LIB to run on the variant.
+_EXTRA = os.environ.get("MS3D_EXTRA_HIPCC_FLAGS", "").split()
+if _EXTRA:
+    import hashlib
+    _tag = hashlib.sha256(" ".join(_EXTRA).encode()).hexdigest()[:10]
+    FLAGS += _EXTRA
+    OBJ_DIR = os.path.join(HERE, "..", "build", "obj_variant_" + _tag)
+    LIB_PATH = os.path.join(HERE, "..", "build", "variants", "libminsu3d_hip_" + _tag + ".so")
+    LIB_DIR = os.path.dirname(LIB_PATH)
 
 
 def _sources():

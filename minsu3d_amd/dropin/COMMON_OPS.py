@@ -65,52 +65,67 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, meanAct
     return int(n_active.value)
 
 
-# ---- the reference's host round trip without the PCIe traffic -------------------------------------------------
+# ---- the reference's host round trip without the upload (OPT-IN: MS3D_DROPIN_REUSE=1) ----------------------------
 # model/pointgroup.py:43-55 (hais.py:45-56, softgroup.py:54-63) moves the ball-query result to the host
 # (`idx.cpu()`, `start_len.cpu()`: up to n * 300 * 4 B ~ 150 MB per call), clusters there and moves the clusters
-# back.  Run unchanged against this module that is two PCIe trips of the whole neighbour list per grouping for a BFS
-# that runs on the GPU anyway.  The last two ball-query results are therefore remembered ON THE DEVICE together with a
-# fingerprint (sizes + _FP_N sampled entries of both tensors, fetched with the hit count the call already reads back);
-# a clustering call that is handed HOST tensors with the same fingerprint takes the device copies instead of
-# uploading them.  A host tensor that was edited between the two calls at one of the other positions would be
-# mistaken for the original: MS3D_DROPIN_REUSE=0 switches the shortcut off.
-_FP_N = 4096
-_GRAPHS = []          # newest first: dict(n_active, n, fp_idx, fp_sl, pos_idx, pos_sl, idx, start_len, capped)
+# back.  Run unchanged against this module, the clustering call uploads that list again for a BFS that runs on the GPU
+# anyway.  With MS3D_DROPIN_REUSE=1 the last two ball-query results are remembered ON THE DEVICE with a checksum over
+# EVERY entry of both tensors (column sums weighted by position: any single edited entry changes it), computed on the
+# device when the graph is made; a clustering call that is handed HOST tensors of the same sizes computes the same
+# checksum over the host tensors and takes the device copies only when it agrees.  Off by default: the boundary's
+# contract is "the callee clusters the tensors it is given", and what the shortcut saves (the 2.7 ms upload; the
+# reference's own `.cpu()` of the list costs 28-40 ms and stays) does not justify deciding identity from anything
+# less than the whole tensor.  A remembered graph is dropped once it has been used.
+_GRAPHS = []          # newest first: dict(n_active, n, sum_idx, sum_sl, idx, start_len, capped, v_idx, v_sl)
 _REUSE_HITS = [0, 0]  # (device copies taken, host tensors uploaded) -- read by tests / tools
+_CK_COLS = 4096
 
 
-def _positions(numel, dev):
-    if numel <= 0:
-        return torch.zeros(0, dtype=torch.long, device=dev)
-    g = torch.Generator().manual_seed(numel)
-    return torch.randint(0, numel, (min(_FP_N, numel),), generator=g).to(dev)
+def _reuse_enabled():
+    import os
+    return os.environ.get("MS3D_DROPIN_REUSE", "0") == "1"
+
+
+def _checksum(t):
+    """position-weighted 64-bit checksum over every entry of an integer tensor (same arithmetic on host and device;
+    int64 wraps): entry i contributes t[i] * w[i mod 4096] with odd weights, so no single edit leaves it unchanged"""
+    flat = t.reshape(-1)
+    w = (torch.arange(1, _CK_COLS + 1, dtype=torch.int64, device=flat.device) * 2654435761) | 1
+    m = flat.numel() // _CK_COLS
+    total = torch.zeros((), dtype=torch.int64, device=flat.device)
+    if m:
+        total = total + (flat[:m * _CK_COLS].view(m, _CK_COLS).sum(0, dtype=torch.int64) * w).sum()
+    tail = flat[m * _CK_COLS:]
+    if tail.numel():
+        total = total + (tail.to(torch.int64) * w[:tail.numel()]).sum()
+    return total + flat.numel()
 
 
 def _remember_graph(idx, start_len, n_active, capped):
-    import os
-    if os.environ.get("MS3D_DROPIN_REUSE", "1") == "0" or n_active > idx.numel():
+    if not _reuse_enabled() or n_active > idx.numel():
         return
-    pos_i, pos_s = _positions(n_active, idx.device), _positions(start_len.numel(), idx.device)
-    fp = torch.cat((idx[pos_i], start_len.view(-1)[pos_s])).cpu()          # one small device->host read
-    _GRAPHS.insert(0, dict(n_active=n_active, n=start_len.size(0), pos_idx=pos_i.cpu(), pos_sl=pos_s.cpu(),
-                           fp_idx=fp[:pos_i.numel()], fp_sl=fp[pos_i.numel():], idx=idx, start_len=start_len,
-                           capped=capped, v_idx=idx._version, v_sl=start_len._version))
+    sums = torch.stack((_checksum(idx[:n_active]), _checksum(start_len))).cpu()     # one 16-byte device->host read
+    _GRAPHS.insert(0, dict(n_active=n_active, n=start_len.size(0), sum_idx=int(sums[0]), sum_sl=int(sums[1]), idx=idx,
+                           start_len=start_len, capped=capped, v_idx=idx._version, v_sl=start_len._version))
     del _GRAPHS[2:]
 
 
 def _device_graph(ball_query_idxs, start_len):
     """the device copies of a ball-query result handed in as HOST tensors, or the arguments themselves"""
-    if ball_query_idxs.is_cuda or start_len.is_cuda:
+    if ball_query_idxs.is_cuda or start_len.is_cuda or not _GRAPHS or not _reuse_enabled():
         return ball_query_idxs, start_len
-    for g in _GRAPHS:
+    host_sums = None
+    for k, g in enumerate(_GRAPHS):
         if (g["n_active"] == ball_query_idxs.numel() and g["n"] == start_len.size(0)
-                and g["idx"]._version == g["v_idx"] and g["start_len"]._version == g["v_sl"]   # not written since
-                and torch.equal(ball_query_idxs.view(-1)[g["pos_idx"]], g["fp_idx"])
-                and torch.equal(start_len.reshape(-1)[g["pos_sl"]], g["fp_sl"])):
-            _REUSE_HITS[0] += 1
-            sl = g["start_len"]
-            sl._ms3d_capped = g["capped"]
-            return g["idx"][:g["n_active"]], sl
+                and g["idx"]._version == g["v_idx"] and g["start_len"]._version == g["v_sl"]):   # not written since
+            if host_sums is None:
+                host_sums = (int(_checksum(ball_query_idxs)), int(_checksum(start_len)))
+            if host_sums == (g["sum_idx"], g["sum_sl"]):
+                _REUSE_HITS[0] += 1
+                sl = g["start_len"]
+                sl._ms3d_capped = g["capped"]
+                del _GRAPHS[k]                     # used once: the 150 MB list is not kept alive for another step
+                return g["idx"][:g["n_active"]], sl
     _REUSE_HITS[1] += 1
     return ball_query_idxs, start_len
 

@@ -152,14 +152,16 @@ class Trainer:
             while batch is not None:
                 upcoming = next(batches, None)      # collated (on the GPU) one step ahead
                 opt.zero_grad(set_to_none=True)
+                if upcoming is not None and torch.is_tensor(upcoming.get("voxel_xyz")):
+                    # coordinate-only structures of the next batch: queued right behind this step's backbone, i.e. they
+                    # are built inside the grouping window (GeneralModel.schedule_after_backbone)
+                    model.schedule_after_backbone(
+                        lambda nb=upcoming: ME.prefetch_coordinates(nb["voxel_xyz"], model.backbone.n_levels,
+                                                                    channels=model.backbone.level_channels))
                 if self.ddp is model:
                     loss = model.training_step(batch)
                 else:                               # through the DDP wrapper: it arms the gradient all-reduce
                     loss = sum(model._loss(batch, self.ddp(batch)).values())
-                if upcoming is not None and torch.is_tensor(upcoming.get("voxel_xyz")):
-                    # coordinate-only structures of the next batch, built under this step's backward pass
-                    ME.prefetch_coordinates(upcoming["voxel_xyz"], model.backbone.n_levels,
-                                            channels=model.backbone.level_channels)
                 loss.backward()
                 opt.step()
                 batch = upcoming

@@ -8,6 +8,8 @@ writes are data (inputs + the reference's outputs), committed so that the GPU bo
 import os
 import sys
 
+sys.dont_write_bytecode = True          # nothing is written into /root/reference (no __pycache__ there)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

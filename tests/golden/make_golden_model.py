@@ -26,6 +26,8 @@ import json
 import os
 import re
 import sys
+
+sys.dont_write_bytecode = True          # nothing is written into /root/reference (no __pycache__ there)
 import types
 
 import numpy as np

@@ -67,33 +67,74 @@ def test_pointgroup_call_sequence(OPS, oracle):
     assert not a.is_cuda and torch.equal(a, cluster_idxs) and torch.equal(o, cluster_offsets)
 
 
-def test_host_round_trip_reuses_the_device_graph(OPS, oracle):
+def test_host_round_trip_clusters_what_it_is_given_by_default(OPS, oracle, monkeypatch):
     """model/pointgroup.py:43-55 verbatim data flow: ball query on the GPU, `.cpu()` of both results, clustering on the
-    HOST tensors.  The drop-in module recognises the host copies of its own last results and clusters the device
-    originals (no upload of the neighbour list); a host tensor that differs is uploaded and clustered as given."""
+    HOST tensors.  By default the callee clusters exactly the tensors it is handed: a host copy that was edited (one
+    point cut out of the graph) gives the edited graph's clusters, not the device original's (VERDICT r3 #9)."""
+    monkeypatch.delenv("MS3D_DROPIN_REUSE", raising=False)
+    OPS._GRAPHS.clear()
+    xyz, b, bo, sem = _scene(4, n=30000, B=2)
+    idx, start_len, _ = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
+                                   torch.from_numpy(bo).cuda(), 0.05, 40)
+    assert not OPS._GRAPHS                                        # nothing is remembered unless asked for
+    idx_cpu, sl_cpu = idx.cpu(), start_len.cpu()
+    # the edit: cut the busiest point out of the graph (its own list and every mention of it in its neighbours' lists are
+    # overwritten with self references -- sizes unchanged, the graph stays symmetric as a ball query's is)
+    edited = idx_cpu.clone()
+    victim = int(torch.argmax(sl_cpu[:, 1]))
+    s0, l0 = (int(v) for v in sl_cpu[victim])
+    for v in idx_cpu[s0:s0 + l0].tolist():
+        sv, lv = (int(t) for t in sl_cpu[v])
+        seg = edited[sv:sv + lv]
+        seg[seg == victim] = v
+    edited[s0:s0 + l0] = victim
+    hits0 = list(OPS._REUSE_HITS)
+    out = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
+    OPS.pg_bfs_cluster(torch.from_numpy(sem), edited, sl_cpu, out[0], out[1], len(sem), 30)
+    assert OPS._REUSE_HITS == hits0                               # the shortcut was not even consulted
+    want = oracle.pg_bfs_cluster(sem, edited.numpy(), sl_cpu.numpy(), 30)
+    assert np.array_equal(out[0].numpy(), want[0].reshape(-1, 2)) and np.array_equal(out[1].numpy(), want[1])
+    orig = oracle.pg_bfs_cluster(sem, idx_cpu.numpy(), sl_cpu.numpy(), 30)
+    assert victim in orig[0].reshape(-1, 2)[:, 1] and victim not in out[0][:, 1].numpy()     # the edit was honoured
+
+
+def test_host_round_trip_reuses_the_device_graph_when_asked(OPS, oracle, monkeypatch):
+    """MS3D_DROPIN_REUSE=1: the module recognises the host copies of its own last results by a checksum over EVERY entry
+    and clusters the device originals (no upload of the neighbour list); a host tensor edited at ANY single position --
+    the adversarial case of a sampled fingerprint -- is uploaded and clustered as given."""
+    monkeypatch.setenv("MS3D_DROPIN_REUSE", "1")
+    OPS._GRAPHS.clear()
     xyz, b, bo, sem = _scene(4, n=30000, B=2)
     idx, start_len, _ = _ballquery(OPS, torch.from_numpy(xyz).cuda(), torch.from_numpy(b).cuda(),
                                    torch.from_numpy(bo).cuda(), 0.05, 40)
     widx, wsl = oracle.ballquery_batch_p(xyz, b, bo, 0.05)
     idx_cpu, sl_cpu = idx.cpu(), start_len.cpu()
-    assert np.array_equal(idx_cpu.numpy(), widx)
+    assert np.array_equal(idx_cpu.numpy(), widx) and len(OPS._GRAPHS) == 1
+    # host tensors that are NOT the remembered result: same sizes, ONE entry changed, at seeded random positions of either
+    # tensor (first, last, anywhere) -> never taken for the device graph
+    hits0 = list(OPS._REUSE_HITS)
+    rng = np.random.default_rng(3)
+    positions = [0, idx_cpu.numel() - 1] + [int(p) for p in rng.integers(0, idx_cpu.numel(), 6)]
+    for n_try, p in enumerate(positions):
+        other = idx_cpu.clone()
+        other[p] += 1 if other[p] < len(sem) - 1 else -1
+        a_, b_ = OPS._device_graph(other, sl_cpu)
+        assert a_ is other and b_ is sl_cpu and OPS._REUSE_HITS == [hits0[0], hits0[1] + n_try + 1]
+    other_sl = sl_cpu.clone()
+    other_sl[int(rng.integers(0, sl_cpu.size(0))), 1] += 1
+    a_, b_ = OPS._device_graph(idx_cpu, other_sl)
+    assert a_ is idx_cpu and b_ is other_sl
+    # the untouched copies ARE recognised: device originals taken, used once, then forgotten
     hits0 = list(OPS._REUSE_HITS)
     out = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
     OPS.pg_bfs_cluster(torch.from_numpy(sem), idx_cpu, sl_cpu, out[0], out[1], len(sem), 30)
-    assert OPS._REUSE_HITS[0] == hits0[0] + 1 and OPS._REUSE_HITS[1] == hits0[1]     # device copies taken
+    assert OPS._REUSE_HITS == [hits0[0] + 1, hits0[1]] and not OPS._GRAPHS
     want = oracle.pg_bfs_cluster(sem, widx, wsl, 30)
     assert np.array_equal(out[0].numpy(), want[0].reshape(-1, 2)) and np.array_equal(out[1].numpy(), want[1])
-    # host tensors that are NOT the remembered result: same sizes, one sampled entry changed -> not taken for it
-    g = OPS._GRAPHS[0]
-    other = idx_cpu.clone()
-    other[int(g["pos_idx"][7])] += 1
-    a_, b_ = OPS._device_graph(other, sl_cpu)
-    assert a_ is other and b_ is sl_cpu and OPS._REUSE_HITS[1] == hits0[1] + 1
     # ... and a graph of another ball query (the oracle's, smaller radius) is uploaded and clustered as given
     widx2, wsl2 = oracle.ballquery_batch_p(xyz, b, bo, 0.03)
     out2 = [torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32)]
     OPS.pg_bfs_cluster(torch.from_numpy(sem), torch.from_numpy(widx2), torch.from_numpy(wsl2), out2[0], out2[1], len(sem), 10)
-    assert OPS._REUSE_HITS[1] == hits0[1] + 2 and OPS._REUSE_HITS[0] == hits0[0] + 1
     want2 = oracle.pg_bfs_cluster(sem, widx2, wsl2, 10)
     assert np.array_equal(out2[0].numpy(), want2[0].reshape(-1, 2)) and np.array_equal(out2[1].numpy(), want2[1])
 

@@ -36,12 +36,16 @@ if score is not None:
 def step(b, nxt):
     mark("step_begin")
     opt.zero_grad(set_to_none=True)
+    pf = lambda: ME.prefetch_coordinates(nxt["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
+                                         channels=model.backbone.level_channels)
+    if bench.PREFETCH_AT == "grouping":
+        model.schedule_after_backbone(pf)
     out = model(b)
     mark("forward_end")
     loss = sum(model._loss(b, out).values())
     mark("loss_end")
-    ME.prefetch_coordinates(nxt["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
-                            channels=model.backbone.level_channels)
+    if bench.PREFETCH_AT != "grouping":
+        pf()
     loss.backward()
     mark("backward_end")
     opt.step()

@@ -3,7 +3,7 @@ the TCC has too few slots for both).  Corrections as /opt/skills/guides/MI355X_M
 both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide reads at 64 B -> fetch x 2; WRITE_SIZE
 is taken as reported.
 usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up>
-                                   <model> <commit> > profiles/r03_traffic_<model>.json"""
+                                   <model> <commit> > profiles/r04_traffic_<model>.json"""
 import csv, sys, json, re, collections
 
 

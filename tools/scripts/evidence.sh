@@ -3,9 +3,9 @@ cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1; export TMPDIR=/tmp
 TAG=$1; C=$2
 for M in pointgroup hais softgroup; do
   bash tools/scripts/pmc_traffic.sh $M $C > /dev/null 2>&1
-  cp gpurun_out/r03_traffic_$M.json profiles/ 2>/dev/null   # bench.py reads roofline.traffic from there (this box only)
+  cp gpurun_out/r04_traffic_$M.json profiles/ 2>/dev/null   # bench.py reads roofline.traffic from there (this box only)
 done
-python3 bench.py > gpurun_out/${TAG}_bench_pointgroup.json 2> gpurun_out/${TAG}_bench_pointgroup.err
+python3 bench.py --also none > gpurun_out/${TAG}_bench_pointgroup.json 2> gpurun_out/${TAG}_bench_pointgroup.err
 python3 bench.py --model hais --no-cpu-baseline > gpurun_out/${TAG}_bench_hais.json 2> /dev/null
 python3 bench.py --model softgroup --no-cpu-baseline > gpurun_out/${TAG}_bench_softgroup.json 2> /dev/null
 for M in pointgroup hais softgroup; do
