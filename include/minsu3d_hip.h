@@ -309,7 +309,18 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                                              stream beside the backward-data chain */,
                                int join /* 1: `stream` waits for the backward-weight before the call returns control
                                            of it; 0: the caller joins the streams before dW is read */,
+                               float *wgrad_slabs /* NULL, or ms3d_spconv_wgrad_ws_floats() floats of the caller's that outlive
+                                                     the call: the backward-weight slabs go there instead of into ws */,
+                               int *wgrad_deferred_nblk /* [host] NULL, or (with wgrad_slabs): the slab reduction is NOT
+                                                           launched; receives the number of slabs to reduce later with
+                                                           ms3d_wgrad_reduce_multi (0: dW is final) */,
                                ms3d_stream_t stream);
+/* The slab reductions dW = sum of slabs of MANY layers in one launch, bit-identical to the per-layer reduction.
+ * descs: DEVICE array of n_desc records {const float *slabs; float *dW; int64_t n (floats per slab); int32_t nblk (slabs);
+ * int32_t block_begin} (32 bytes each) in ascending block order; a layer takes ms3d_wgrad_reduce_blocks() blocks and sets
+ * bit 31 of block_begin when that call reports the 16-byte geometry (*wide = 1); total_blocks = their sum. */
+int ms3d_wgrad_reduce_blocks(long n, const float *slabs, const float *dW, int *wide /*[host]*/);
+int ms3d_wgrad_reduce_multi(const void *descs, int n_desc, int total_blocks, ms3d_stream_t stream);
 
 /* BatchNorm1d over rows, training mode (biased var for normalisation, unbiased into running_var) */
 int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, const float *gamma, const float *beta,

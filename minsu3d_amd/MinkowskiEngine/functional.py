@@ -32,6 +32,25 @@ class SkipLink:
         self.armed = False     # set by the head's forward: only then may the tail keep its dy back
 
 
+class GroupFlushFn(torch.autograd.Function):
+    """Identity on a GROUP of convolution kernels whose backward runs once, after the last layer of the group has produced
+    its weight gradient: there the group's queued backward-weight slab reductions are launched as ONE kernel
+    (backend.WgradQueue) and the -- now complete -- gradients go on to the parameters.  Everything downstream of a
+    parameter gradient (accumulation into an existing .grad, DistributedDataParallel's bucket hooks, the optimizer) sits
+    behind this node, so it never sees an unreduced dW.  Built per forward by modules.prepare_conv_weights."""
+
+    @staticmethod
+    def forward(ctx, queue, *kernels):
+        ctx.queue = queue
+        ctx.set_materialize_grads(False)
+        return tuple(k.view_as(k) for k in kernels)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.queue.flush()
+        return (None,) + grads
+
+
 class SparseConvFn(torch.autograd.Function):
     """(y, stats) = conv(act(x)) [+ residual];  stats = per-block (sum, sum of squares) of y from the kernel epilogue
     (non-differentiable side output that lets the next BatchNorm skip its statistics pass)"""
@@ -50,6 +69,10 @@ class SparseConvFn(torch.autograd.Function):
         if stats is None:
             stats = x.new_zeros(0)
         ctx.spec, ctx.bn, ctx.wf_buf, ctx.has_res = spec, bn, wf_buf, residual is not None
+        # (deferred slab reduction: the queue of this kernel's group, stamped by prepare_conv_weights for this forward)
+        defer = getattr(W, "_ms3d_defer", None)
+        ctx.defer = defer[0] if (defer is not None and defer[1] == getattr(be, "weight_token", None)) else None
+        ctx.w_direct = W.is_leaf or ctx.defer is not None    # nobody computes on dW before the parameter / the flush node
         if skip is not None:     # None | ("head", SkipLink) | ("tail", SkipLink)
             if skip[0] == "head":
                 skip[1].armed = True
@@ -82,9 +105,16 @@ class SparseConvFn(torch.autograd.Function):
                                          pre=(bn["scale"], bn["shift"]), pre_relu=False)
         else:
             fused = add is not None and ctx.needs_input_grad[0] and be.fuses_dx_add(bn)
+            extra = {"dx_add": add} if fused else {}
+            if ctx.defer is not None:
+                extra["defer"] = ctx.defer
+            elif (not ctx.w_direct or (W.is_leaf and W.grad is not None)) and hasattr(be, "wgrad_stream_mode") \
+                    and be.wgrad_stream_mode() == 2:
+                # MS3D_WGRAD_STREAM=2 only: dW is consumed on this stream right away (a slice of a padded kernel's
+                # gradient, the accumulation into an existing .grad): this layer's backward-weight is joined now
+                extra["join_now"] = True
             dx, dgb, dW = be.conv_layer_backward(x, dy, ctx.wf_buf, spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout,
-                                                 spec.K, spec.cin, spec.cout, bn, ctx.needs_input_grad[0],
-                                                 **({"dx_add": add} if fused else {}))
+                                                 spec.K, spec.cin, spec.cout, bn, ctx.needs_input_grad[0], **extra)
             if fused:
                 add = None
         if add is not None and dx is not None:

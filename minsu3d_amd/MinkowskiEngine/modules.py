@@ -26,8 +26,32 @@ class _ConvBase(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-s, s)
 
+    def _kernel(self):
+        """the kernel this forward uses: the parameter, or -- inside a prepare_conv_weights window in training -- its
+        alias behind the group's GroupFlushFn node (same storage; the gradient reaches the parameter through that node)"""
+        eff = self.__dict__.get("_kernel_eff")
+        if eff is not None and eff[1] == getattr(get_backend(), "weight_token", None):
+            return eff[0]
+        return self.kernel
+
     def extra_repr(self):
         return f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
+
+
+def _flush_group(name):
+    """Which deferred-reduction group a convolution belongs to, from its module path.  A group's slab reductions run when
+    its LAST layer has finished its backward pass, and only then do its gradients reach the parameters (and a
+    data-parallel wrapper's bucket hooks), so the groups follow the order of the backward pass and keep the bulk of the
+    bytes early: the proposal network first; then the decoder side of the three finest U-Net levels; then everything
+    from level 3 down (~90 % of the parameter bytes, complete half way through the pass); last the encoder side of the
+    finest levels and the input convolution (~1.5 MB at m = 16)."""
+    parts = name.split(".")
+    if "backbone" not in parts:
+        return 0
+    depth = parts.count("u")
+    if depth >= 3:
+        return 2
+    return 1 if ("blocks_tail" in parts or "deconv" in parts) else 3
 
 
 def prepare_conv_weights(root):
@@ -35,6 +59,8 @@ def prepare_conv_weights(root):
     launch per layer inside each convolution call; ~90 per U-Net step) and stamp the parameters.  The stamp is valid
     until `release_conv_weights()`: call the pair around a forward pass during which the weights do not change
     (GeneralModel.__call__ does).  Convolutions called outside such a window lay out their own weights as before.
+    In training the convolutions are also handed their kernels through `GroupFlushFn` nodes (functional.py): the slab
+    reductions behind the backward-weight kernels of a whole group of layers then run as one launch.
     Not part of ME's API."""
     be = get_backend()
     if not hasattr(be, "prep_weights_multi") or os.environ.get("MS3D_WEIGHT_MULTI", "1") == "0":
@@ -44,8 +70,11 @@ def prepare_conv_weights(root):
     if convs is None:
         # (walking the module tree costs 0.7 ms per step on the 400-module networks; the set of convolutions of a built
         # model does not change -- `del model._ms3d_convs` after surgery on it)
-        convs = root.__dict__["_ms3d_convs"] = tuple(m for m in root.modules() if isinstance(m, _ConvBase))
-    for m in convs:
+        named = [(n, m) for n, m in root.named_modules() if isinstance(m, _ConvBase)]
+        convs = root.__dict__["_ms3d_convs"] = tuple(m for _, m in named)
+        root.__dict__["_ms3d_conv_groups"] = tuple(_flush_group(n) for n, _ in named)
+    for m, grp in zip(convs, root.__dict__["_ms3d_conv_groups"]):
+        m.__dict__.pop("_kernel_eff", None)
         if m.kernel.is_cuda:
             K, cin, cout = m.kernel_volume, m.in_channels, m.out_channels
             if m.kernel.dim() == 2:
@@ -54,10 +83,27 @@ def prepare_conv_weights(root):
             if buf is None or buf.device != m.kernel.device:
                 buf = m.__dict__["_wf_buf"] = torch.empty(be.wf_floats(K, cin, cout), dtype=torch.float32, device=m.kernel.device)
             # same orientation rule as the forward() of the module: 3x3x3 maps mirror their offsets in backward-data
-            layers.append((m.kernel, buf, K, cin, cout, m.kernel_size == 3 and m.stride == 1))
-    be.prep_weights_multi(layers)
+            layers.append((m.kernel, buf, K, cin, cout, m.kernel_size == 3 and m.stride == 1, m, grp))
+    be.prep_weights_multi([l[:6] for l in layers])
+    token = be.weight_token
+    defer = torch.is_grad_enabled() and hasattr(be, "wgrad_queue")
+    if defer:
+        groups = {}
+        for w, buf, *_, m, grp in layers:
+            if w.requires_grad:
+                groups.setdefault(grp, []).append((w, buf, m))
+        for g, members in groups.items():
+            queue = be.wgrad_queue()
+            if queue is None:
+                defer = False
+                break
+            eff = Fn.GroupFlushFn.apply(queue, *[w for w, _, _ in members])
+            for e, (w, buf, m) in zip(eff, members):
+                e._ms3d_wf = (buf, token)
+                e._ms3d_defer = (queue, token)
+                m.__dict__["_kernel_eff"] = (e, token)
     for w, buf, *_ in layers:
-        w._ms3d_wf = (buf, be.weight_token)
+        w._ms3d_wf = (buf, token)
 
 
 def release_conv_weights():
@@ -91,7 +137,7 @@ class MinkowskiConvolution(_ConvBase):
             out_ts = ts
         else:
             raise NotImplementedError((self.kernel_size, self.stride))
-        feats, kernel, pending = x._F, self.kernel, x._pending
+        feats, kernel, pending = x._F, self._kernel(), x._pending
         if cin % 16 != 0 and cin < 16 and self.kernel_volume > 1 and pending is None and spec.vout >= 30000:
             # the network's input convolution (6 channels) at full resolution: zero-padding rows and weights to one
             # 16-channel chunk lets it take the aligned pair-list kernels (16-byte row gathers) instead of the
@@ -116,7 +162,7 @@ class MinkowskiConvolutionTranspose(_ConvBase):
         fine = ts // 2
         down, up = cm.k2(fine)  # cached by the encoder's strided convolution
         spec = Fn.ConvSpec(up, down, cm.size(ts), cm.size(fine), 8, self.in_channels, self.out_channels, False)
-        y, stats = Fn.conv(x._F, self.kernel, spec, x._pending, want_stats=self.training)
+        y, stats = Fn.conv(x._F, self._kernel(), spec, x._pending, want_stats=self.training)
         return x._like(y, tensor_stride=fine, stats=stats)
 
 

@@ -402,7 +402,7 @@ _VP, _I = C.c_void_p, C.c_int
 _FAST_ARGTYPES = {
     "ms3d_spconv_layer_forward": [_VP] * 3 + [_I] * 5 + [_VP] * 2 + [_I] + [_VP] * 5 + [_VP] * 2 + [_VP] * 2 + [_VP],
     "ms3d_spconv_layer_backward": [_VP] * 5 + [_I] * 5 + [_VP] * 4 + [_I] * 3 + [_VP] * 5 + [_VP] * 4 + [_VP] * 4 +
-                                  [_VP, _VP, _I, _VP],
+                                  [_VP, _VP, _I, _VP, _VP, _VP],
     "ms3d_bn_finalize": [_VP, _I, C.c_long, _I, C.c_float, C.c_float] + [_VP] * 4 + [_VP] * 4 + [_VP],
 }
 
@@ -475,6 +475,53 @@ class KernelTimer:
             g["launches"] += 1; g["ms"] += ms; g["bytes"] += nb; g["flops"] += flops
         self.records = []
         return out
+
+
+class WgradQueue:
+    """Backward-weight slab reductions of a GROUP of layers, run as ONE launch (ms3d_wgrad_reduce_multi) when the group's
+    last layer has finished its backward pass (MinkowskiEngine/functional.py, GroupFlushFn) instead of one ~5 us launch
+    per layer behind every backward-weight kernel (~90 per PointGroup step, each with a dependent-launch gap).  The
+    layers' dW tensors are handed to autograd unreduced; the flush fills them in before anybody downstream (gradient
+    accumulation, a data-parallel wrapper's bucket hooks, the optimizer) sees them.  Summation order per element is the
+    per-layer kernels': bit-identical gradients."""
+    _host = _host_np = _dev = None      # descriptor staging, shared by all queues of the process (one device per process)
+    _turn = 0
+    RING = 16                           # pinned staging slots: a slot is rewritten 16 flushes (~4 steps) later
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.items = []          # (slabs tensor, dW tensor, n floats per slab, slabs)
+
+    def add(self, slabs, dW, n, nblk):
+        self.items.append((slabs, dW, int(n), int(nblk)))
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        m = len(items)
+        dev = items[0][1].device
+        cls = WgradQueue
+        if cls._host is None or cls._host[0].shape[0] < m or cls._dev[0].device != dev:
+            cap = max(2 * m, 128)
+            cls._host = [torch.empty((cap, 4), dtype=torch.int64).pin_memory() for _ in range(self.RING)]
+            cls._host_np = [h.numpy().view(np.uint64) for h in cls._host]
+            cls._dev = [torch.empty((cap, 4), dtype=torch.int64, device=dev) for _ in range(self.RING)]
+        turn = cls._turn
+        cls._turn = (turn + 1) % self.RING
+        hn = cls._host_np[turn]
+        begin = 0
+        for i, (slabs, dW, n, nblk) in enumerate(items):
+            ps, pw = slabs.data_ptr(), dW.data_ptr()
+            wide = n >= 32768 and (n & 3) == 0 and (ps & 15) == 0 and (pw & 15) == 0   # ms3d_wgrad_reduce_blocks
+            blocks = -(-(n // 4) // 64) if wide else -(-n // 16)
+            hn[i, 0], hn[i, 1], hn[i, 2] = ps, pw, n
+            hn[i, 3] = (nblk & 0xffffffff) | (((begin | (0x80000000 if wide else 0)) & 0xffffffff) << 32)
+            begin += blocks
+        cls._dev[turn][:m].copy_(cls._host[turn][:m], non_blocking=True)
+        _lib.check(self.lib.ms3d_wgrad_reduce_multi(_lib.ptr(cls._dev[turn]), m, int(begin), _lib.stream_handle()),
+                   "ms3d_wgrad_reduce_multi")
+        # `items` (the slab tensors) die here: the caching allocator reuses them stream-ordered, behind the launch
 
 
 class _HipEngine:
@@ -703,7 +750,7 @@ class _HipEngine:
         v = cache.get(k)
         if v is None:
             fn = getattr(self.lib, what)
-            if what in ("ms3d_spconv_wf_floats", "ms3d_spconv_layer_ws_floats"):
+            if what in ("ms3d_spconv_wf_floats", "ms3d_spconv_layer_ws_floats", "ms3d_spconv_wgrad_ws_floats"):
                 fn.restype = C.c_size_t
             v = cache[k] = fn(*[int(a) for a in key])
         return v
@@ -737,9 +784,22 @@ class _HipEngine:
         _lib.check(self.lib.ms3d_spconv_prep_weights_multi(_lib.ptr(cached[1]), len(layers), int(cached[2]),
                                                            _lib.stream_handle()), "ms3d_spconv_prep_weights_multi")
         self.weight_token += 1
+        if self.__dict__.get("_wgrad_join_queued"):
+            # MS3D_WGRAD_STREAM=2: a backward pass that raised never ran its end-of-pass callback -- join here, or no
+            # later pass would queue one
+            self._wgrad_join_queued = False
+            torch.cuda.current_stream().wait_stream(wgrad_stream(layers[0][0].device))
 
     def release_weights(self):
         self.weight_token += 1
+
+    def wgrad_queue(self):
+        """a fresh WgradQueue, or None when deferred slab reductions are off (MS3D_WGRAD_DEFER=0, or backward-weight on
+        its own stream: the flush would have to run there)"""
+        on = self.__dict__.get("_wgrad_defer")
+        if on is None:
+            on = self._wgrad_defer = os.environ.get("MS3D_WGRAD_DEFER", "1") != "0" and self.wgrad_stream_mode() == 0
+        return WgradQueue(self.lib) if on else None
 
     def conv_layer_forward(self, x, W3, nbr_fwd, vout, K, cin, cout, mirror_bwd, pre, pre_relu, residual, bias,
                            want_stats, wf_ready=None):
@@ -765,10 +825,13 @@ class _HipEngine:
             ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")
         return y, stats, wf_buf
 
-    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None):
+    def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None,
+                            defer=None, join_now=False):
         """-> (dx or None, dgb [2,cin] = (dbeta, dgamma) or None, dW [K,cin,cout]).  dx_add [vin, cin]: a gradient that
         reaches x over a skip connection, added to dx inside the BatchNorm-backward pass / the residual epilogue (needs
-        training-mode statistics when a BatchNorm is fused: `fuses_dx_add`)"""
+        training-mode statistics when a BatchNorm is fused: `fuses_dx_add`).  defer: a WgradQueue -- dW is returned
+        UNREDUCED and completed by the queue's flush.  join_now: with MS3D_WGRAD_STREAM=2, make the caller's stream wait
+        for this layer's backward-weight (somebody consumes dW on it right after this call)."""
         x = self._dev(x); dy = self._dev(dy)
         dev = x.device
         ws = self.ws.get("layer", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
@@ -786,8 +849,20 @@ class _HipEngine:
         ev2, ev3 = tok if tok is not None else (None, None)
         mode = self.wgrad_stream_mode()
         side = wgrad_stream(dev) if mode else None
-        ws2 = self.ws.get("layer_wgrad", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev) \
-            if side is not None else None
+        ws2 = None
+        if side is not None:
+            # the second stream's slab area is allocated UNDER that stream: when a larger layer makes it grow, the old
+            # block goes back to the side stream's pool and is reused behind the kernels still writing it
+            with torch.cuda.stream(side):
+                ws2 = self.ws.get("layer_wgrad", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
+            defer = None
+        slabs, n_defer = None, None
+        if defer is not None:
+            if "_defer_n" not in self.__dict__:
+                self._defer_n = C.c_int(0)
+                self._defer_n_addr = C.addressof(self._defer_n)
+            slabs = torch.empty(self._geom("ms3d_spconv_wgrad_ws_floats", vout, K, cin, cout), dtype=torch.float32, device=dev)
+            n_defer = self._defer_n_addr
         _lib.check(self._fast("ms3d_spconv_layer_backward")(
             _p(x), _p(dy), _p(wf_buf), _p(nbr_fwd), _p(nbr_bwd), int(vin), int(vout), int(K),
             int(cin), int(cout), _p(bn["scale"] if has_bn else None), _p(bn["shift"] if has_bn else None),
@@ -795,12 +870,16 @@ class _HipEngine:
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
             _p(_f32(dx_add) if (dx_add is not None and need_dx) else None), _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
             _p(plb[1]), ev0, ev1, ev2, ev3, _p(ws2), side.cuda_stream if side is not None else None,
-            int(mode == 1), _lib.stream_handle()), "ms3d_spconv_layer_backward")
+            int(mode == 1 or (mode == 2 and join_now)), _p(slabs), n_defer, _lib.stream_handle()),
+            "ms3d_spconv_layer_backward")
+        if slabs is not None and self._defer_n.value > 0:
+            defer.add(slabs, dW, K * cin * cout, self._defer_n.value)
         if mode == 2:
             # the second stream runs free until the end of the backward pass: the allocator must not hand x / dy to
             # somebody else while it still reads them, and the pass ends with the join
             x.record_stream(side); dy.record_stream(side); dW.record_stream(side)
-            self._queue_wgrad_join(side)
+            if not join_now:
+                self._queue_wgrad_join(side)
         return (dx if need_dx else None), dgb, dW
 
     @staticmethod

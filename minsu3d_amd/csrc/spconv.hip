@@ -23,6 +23,7 @@
 // the reduction dimension, several offsets per wave sharing the dout fragment.
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include "common.h"
 #include "../../include/minsu3d_hip.h"
 
@@ -2148,6 +2149,80 @@ static inline void launch_wgrad_reduce(const float *partial, int nblk, long n, f
         wgrad_reduce_kernel<<<ms3d_divup(n, 16), 256, 0, stream>>>(partial, nblk, n, dW);
 }
 
+// ONE launch for the slab reductions of many layers (ms3d_wgrad_reduce_multi): a block finds its layer in the
+// descriptor table (blocks are numbered layer after layer) and does exactly what a block of wgrad_reduce_kernel /
+// wgrad_reduce4_kernel does for that layer -- same lanes, same summation order, bit-identical dW.
+struct WgradReduceDesc {
+    const float *slabs;
+    float *dW;
+    long n;           // floats per slab
+    int nblk;         // slabs
+    int block_begin;  // first block of this layer; bit 31 set: the 16-byte kernel's geometry (64 float4 groups per block)
+};
+static_assert(sizeof(WgradReduceDesc) == 32, "descriptor layout is part of the C ABI (host code packs it)");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradReduceDesc *__restrict__ descs, int n_desc)
+{
+    __shared__ float s_sum[16][17];
+    int lo = 0, hi = n_desc - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {        // last descriptor whose first block is <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if ((descs[mid].block_begin & 0x7fffffff) <= blk) lo = mid; else hi = mid - 1;
+    }
+    const WgradReduceDesc d = descs[lo];
+    const int b0 = blk - (d.block_begin & 0x7fffffff);
+    const float *__restrict__ partial = d.slabs;
+    const int nblk = d.nblk;
+    if (d.block_begin < 0) {
+        const long n4 = d.n >> 2;
+        const int g = threadIdx.x & 15, sl = (threadIdx.x >> 4) & 3, sub = threadIdx.x >> 6;
+        const long e4 = (long)b0 * 64 + sub * 16 + g;
+        const float4 *p4 = reinterpret_cast<const float4 *>(partial);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e4 < n4) {
+            int b = sl;
+            for (; b + 12 < nblk; b += 16) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = p4[(size_t)(b + 4 * u) * n4 + e4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            for (; b < nblk; b += 4) {
+                const float4 v = p4[(size_t)b * n4 + e4];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+#pragma unroll
+        for (int dd = 16; dd <= 32; dd <<= 1) {
+            s.x += __shfl_xor(s.x, dd, 64); s.y += __shfl_xor(s.y, dd, 64);
+            s.z += __shfl_xor(s.z, dd, 64); s.w += __shfl_xor(s.w, dd, 64);
+        }
+        if (sl == 0 && e4 < n4) reinterpret_cast<float4 *>(d.dW)[e4] = s;
+        return;
+    }
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long n = d.n, e = (long)b0 * 16 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        int b = sl;
+        for (; b + 16 < nblk; b += 32) {
+            s0 += partial[(size_t)b * n + e];
+            s1 += partial[(size_t)(b + 16) * n + e];
+        }
+        if (b < nblk) s0 += partial[(size_t)b * n + e];
+    }
+    s_sum[sl][el] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) t += s_sum[j][threadIdx.x];
+        d.dW[e] = t;
+    }
+}
+
 template <int KG, int NBT>
 int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 {
@@ -3097,12 +3172,29 @@ int ms3d_spconv_wgrad_row_chunks(int Vout)
     return chunks < 1 ? 1 : chunks;
 }
 
+// defer_nblk != NULL: the slab reduction is NOT launched; *defer_nblk = number of slabs left in partial_ws (0: dW is
+// already final), to be reduced later by ms3d_wgrad_reduce_multi
+static int spconv_backward_weight_impl(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
+                                       float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
+                                       float *partial_ws, const int *ol_kt_start, const int *ol_entries, int *defer_nblk,
+                                       ms3d_stream_t stream_);
+
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                 float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                 float *partial_ws, const int *ol_kt_start, const int *ol_entries, ms3d_stream_t stream_)
 {
+    return spconv_backward_weight_impl(in, dout, nbr, Vout, K, Cin, Cout, dW, pre_scale, pre_shift, pre_relu, partial_ws,
+                                       ol_kt_start, ol_entries, nullptr, stream_);
+}
+
+static int spconv_backward_weight_impl(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
+                                       float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
+                                       float *partial_ws, const int *ol_kt_start, const int *ol_entries, int *defer_nblk,
+                                       ms3d_stream_t stream_)
+{
     hipStream_t stream = (hipStream_t)stream_;
     const long n = (long)K * Cin * Cout;
+    if (defer_nblk) *defer_nblk = 0;
     if (Vout <= 0) {
         MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * n, stream));
         return 0;
@@ -3159,6 +3251,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
            : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
         if (rc) return rc;
+        if (defer_nblk) { *defer_nblk = nblk; return 0; }
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
         MS3D_LAUNCH_CHECK();
         return 0;
@@ -3197,6 +3290,7 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
         rc = nb == 3 ? launch_wgrad_bf3<14, 3, 1>(q, nblk, stream) : nb == 4 ? launch_wgrad_bf3<9, 4, 1>(q, nblk, stream)
            : nb <= 6 ? launch_wgrad_bf3<9, 3, 2>(q, nblk, stream) : launch_wgrad_bf3<9, 4, 2>(q, nblk, stream);
         if (rc) return rc;
+        if (defer_nblk) { *defer_nblk = nblk; return 0; }
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
         MS3D_LAUNCH_CHECK();
         return 0;
@@ -3214,7 +3308,27 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
     else if (nb <= 12) rc = launch_wgrad<2, 12>(p, nblk, stream);
     else rc = launch_wgrad<2, 14>(p, nblk, stream);
     if (rc) return rc;
+    if (defer_nblk) { *defer_nblk = nblk; return 0; }
     launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// slab reductions of many layers in one launch.  descs (DEVICE memory): n_desc records of 32 bytes
+// {const float *slabs; float *dW; int64 n; int32 nblk; int32 block_begin | geometry bit} in ascending block order,
+// block counts from ms3d_wgrad_reduce_blocks (which also tells the geometry bit)
+int ms3d_wgrad_reduce_blocks(long n, const float *slabs, const float *dW, int *wide)
+{
+    const bool w = n >= 32768 && (n & 3) == 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dW & 15) == 0;
+    if (wide) *wide = w ? 1 : 0;
+    return w ? ms3d_divup(n / 4, 64) : ms3d_divup(n, 16);
+}
+
+int ms3d_wgrad_reduce_multi(const void *descs, int n_desc, int total_blocks, ms3d_stream_t stream)
+{
+    if (n_desc <= 0 || total_blocks <= 0) return 0;
+    wgrad_reduce_multi_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(static_cast<const WgradReduceDesc *>(descs),
+                                                                           n_desc);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -3369,15 +3483,22 @@ float ms3d_event_elapsed_ms(void *start, void *stop)
 // already issued keeps the state it captured)
 static hipEvent_t order_event()
 {
-    static hipEvent_t pool[256];
-    static bool ready[256];
-    static std::atomic<unsigned> next{0};
-    const unsigned i = next.fetch_add(1) & 255u;
-    if (!ready[i]) {
-        if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        ready[i] = true;
+    // one pool per device (an event belongs to the device that was current when it was created), creation under a lock
+    // (a process-wide pool with a plain ready flag was wrong for several devices / threads per process)
+    constexpr int MAX_DEV = 16, POOL = 256;
+    static hipEvent_t pool[MAX_DEV][POOL];
+    static bool ready[MAX_DEV][POOL];
+    static unsigned next[MAX_DEV];
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    const unsigned i = next[dev]++ & (POOL - 1);
+    if (!ready[dev][i]) {
+        if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        ready[dev][i] = true;
     }
-    return pool[i];
+    return pool[dev][i];
 }
 
 int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_buf, const int *nbr_fwd,
@@ -3386,7 +3507,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                int need_dx, float *dx, const float *dx_add, float *dgb, float *dW, float *ws,
                                const int *ol_fwd_kt_start, const int *ol_fwd_entries, const int *pl_bwd_tile_start,
                                const int *pl_bwd_entries, void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop,
-                               float *ws_wgrad, ms3d_stream_t wgrad_stream, int join, ms3d_stream_t stream)
+                               float *ws_wgrad, ms3d_stream_t wgrad_stream, int join, float *wgrad_slabs,
+                               int *wgrad_deferred_nblk, ms3d_stream_t stream)
 {
     const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
     const float *wft = wf_buf + 3 * nwf, *wfts = wf_buf + 4 * nwf;
@@ -3401,8 +3523,11 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
     hipEvent_t done = nullptr;
     auto run_wgrad = [&]() -> int {
         if (ev_wg_start) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_start, side));
-        int r = ms3d_spconv_backward_weight(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu, slabs,
-                                            ol_fwd_kt_start, ol_fwd_entries, (ms3d_stream_t)side);
+        // wgrad_slabs: a slab area of the caller's that outlives this call; with wgrad_deferred_nblk the slab reduction is
+        // left to one ms3d_wgrad_reduce_multi launch over many layers
+        int r = spconv_backward_weight_impl(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu,
+                                            wgrad_slabs ? wgrad_slabs : slabs, ol_fwd_kt_start, ol_fwd_entries,
+                                            wgrad_slabs ? wgrad_deferred_nblk : nullptr, (ms3d_stream_t)side);
         if (ev_wg_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_stop, side));
         return r;
     };

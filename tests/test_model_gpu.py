@@ -368,28 +368,54 @@ def _ddp_gpu_worker(rank, world, port, q):
     dev = torch.device("cuda", 0)
     model = bm(seed=0).to(dev)
     model.train()
+    # (fixed proposal-grid placement: the step is evaluated twice below and must be the same function both times)
+    model.voxelization_rand = (torch.tensor([0.3, 0.6, 0.9], device=dev), torch.tensor([0.1, 0.2, 0.3], device=dev))
     ddp = wrap_ddp(model, dev, find_unused_parameters=False)
     opt = model.configure_optimizers()
-    losses = []
+    from minsu3d_amd import backend as ms_backend
+    be = ms_backend.get_backend()
+    losses, grad_err = [], 0.0
     for step in range(3):
         seeds = shard_scene_seeds(step=step, scenes_per_rank=2, rank=rank, world_size=world)
         batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb(tuple(seeds)).items()}
         opt.zero_grad(set_to_none=True)
         loss = sum(model._loss(batch, ddp(batch)).values())
         loss.backward()
+        if step == 0:
+            # what the bucket hooks all-reduced must be the COMPLETE gradients: the backward-weight slab reductions are
+            # deferred to one launch per layer group (GroupFlushFn), and a hook that fired before its group's flush
+            # would have averaged unreduced slabs -- identically on both ranks, so "the ranks agree" would not notice.
+            # Reference: every rank's local gradients without the wrapper and without the deferral, averaged by hand.
+            assert be.wgrad_queue() is not None                      # the deferral is what ran above
+            got = torch.cat([p.grad.detach().flatten() for p in model.parameters()]).clone()
+            opt.zero_grad(set_to_none=True)
+            be._wgrad_defer = False
+            try:
+                sum(model._loss(batch, model(batch)).values()).backward()
+            finally:
+                be._wgrad_defer = True
+            local = torch.cat([p.grad.detach().flatten() for p in model.parameters()])
+            parts = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            want = torch.stack(parts).mean(0)
+            grad_err = float((got - want).abs().max() / want.abs().max())
+            for p_, g_ in zip(model.parameters(), got.split([p.numel() for p in model.parameters()])):
+                p_.grad.copy_(g_.view_as(p_))                        # carry on with the wrapper's gradients
         opt.step()
         losses.append(float(loss))
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    q.put((rank, type(opt).__module__, losses, all(torch.equal(gathered[0], t) for t in gathered), bool(torch.isfinite(flat).all())))
+    q.put((rank, type(opt).__module__, losses, all(torch.equal(gathered[0], t) for t in gathered),
+           bool(torch.isfinite(flat).all()), grad_err))
     dist.destroy_process_group()
 
 
 def test_ddp_two_ranks_on_one_gpu_stay_in_step(tmp_path):
     """the data-parallel training path on the GPU box: two ranks (gloo, sharing the one device -- RCCL refuses that) run
-    three steps on disjoint scenes with DistributedDataParallel (bucket-view gradients) and the one-launch Adam; their
-    parameters are bit-identical afterwards"""
+    three steps on disjoint scenes with DistributedDataParallel (bucket-view gradients), the deferred backward-weight slab
+    reductions and the one-launch Adam; the all-reduced gradients are the hand-made average of the ranks' local ones and
+    the parameters are bit-identical afterwards"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -404,6 +430,9 @@ def test_ddp_two_ranks_on_one_gpu_stay_in_step(tmp_path):
     assert res[0][1] == res[1][1] == "minsu3d_amd.optim"      # the library's Adam is what stepped
     assert res[0][2] != res[1][2]                             # different scenes, different losses
     assert res[0][3] and res[1][3] and res[0][4]              # identical, finite parameters on both ranks
+    # the all-reduced gradients are the average of the ranks' complete local gradients (training-mode statistics are
+    # summed with LDS float atomics, so two evaluations of the same step differ in the last bits: ~1e-6 measured)
+    assert max(res[0][5], res[1][5]) <= 1e-3, (res[0][5], res[1][5])
 
 
 def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
@@ -436,3 +465,47 @@ def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
                     assert (g[n] - grads[n]).abs().max().item() <= 1e-4 * scale + 1e-12, (mode, n)
     finally:
         be._wgrad_mode = 0
+
+
+def test_deferred_slab_reduction_gives_the_same_gradients(monkeypatch):
+    """The backward-weight slab reductions of a group of layers run as ONE launch when the group's last layer is done
+    (modules.prepare_conv_weights -> functional.GroupFlushFn -> backend.WgradQueue) instead of one launch per layer:
+    same kernels' slabs, same per-element summation order.  Whole-model gradients with and without the deferral
+    (eval-mode statistics: no float-atomic noise in the BatchNorms), flush count = layer groups, every convolution's
+    reduction accounted for; with an existing .grad (accumulation) the sum is right too."""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend, WgradQueue
+    be = HipBackend()
+    backend.set_backend(be)
+    u = tuple(t.cuda() for t in (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3])))
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((21, 22)).items()}
+    m = build_model(seed=5).cuda()
+    m.voxelization_rand = u
+    m.eval()
+    flushed = []
+    real_flush = WgradQueue.flush
+    monkeypatch.setattr(WgradQueue, "flush", lambda self: (flushed.append(len(self.items)), real_flush(self))[1])
+
+    def grads(defer, accumulate=False):
+        be._wgrad_defer = defer
+        if not accumulate:
+            m.zero_grad(set_to_none=True)
+        sum(m._loss(b, m(b)).values()).backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        want = grads(False)
+        assert not flushed
+        got = grads(True)
+        n_convs = sum(1 for mod in m.modules() if hasattr(mod, "kernel_volume"))
+        assert 2 <= len(flushed) <= 4 and 0.8 * n_convs <= sum(flushed) <= n_convs, (flushed, n_convs)
+        assert got.keys() == want.keys()
+        for n in got:
+            scale = want[n].abs().max().item()
+            assert (got[n] - want[n]).abs().max().item() <= 1e-4 * scale + 1e-12, n
+        twice = grads(True, accumulate=True)             # .grad exists: autograd accumulates behind the flush node
+        for n in twice:
+            scale = want[n].abs().max().item()
+            assert (twice[n] - 2 * want[n]).abs().max().item() <= 2e-4 * scale + 1e-12, n
+    finally:
+        be._wgrad_defer = None

@@ -196,6 +196,16 @@ def _check_layer_entry(be, oracle, K, cin, cout, vin, vout, mirror, x, W, g, res
     got_gb = dgb.cpu().numpy()
     want_gb = np.stack([s1, s2])          # (dbeta, dgamma)
     assert np.allclose(got_gb, want_gb, rtol=1e-3, atol=1e-3 * np.abs(want_gb).max())
+    # deferred slab reduction (one ms3d_wgrad_reduce_multi launch for many layers): bit-identical to the per-layer launch
+    from minsu3d_amd.backend import WgradQueue
+    queue = WgradQueue(be.lib)
+    _, _, dW_a = be.conv_layer_backward(xd, gd, wf_buf, nbr_d, nbr_bwd_d, vin, vout, K, cin, cout, bn, True, defer=queue)
+    _, _, dW_b = be.conv_layer_backward(xd, gd, wf_buf, nbr_d, nbr_bwd_d, vin, vout, K, cin, cout, None, False, defer=queue)
+    n_queued = len(queue.items)
+    queue.flush()
+    assert n_queued == 2 and not queue.items
+    assert torch.equal(dW_a, dW)
+    assert rel_err(dW_b.cpu(), torch.from_numpy(oracle.conv_bwd_weight(x, g, nbr, K))) < RTOL
     # without a BatchNorm in front (the network's first convolution; DenseLinear): dx is the plain backward-data
     y0, _, wf0 = be.conv_layer_forward(xd, Wd, nbr_d, vout, K, cin, cout, mirror, None, False, None, None, False)
     assert rel_err(y0.cpu(), torch.from_numpy(oracle.conv_fwd(x, W, nbr))) < RTOL
