@@ -376,6 +376,22 @@ int ms3d_adam_step_multi(const int *chunks, int n_chunks, void *const *p_ptrs, c
                          void *const *m_ptrs, void *const *v_ptrs, const long *sizes, const float *coef, float beta1,
                          float beta2, float eps, float weight_decay, ms3d_stream_t stream);
 
+/* ---- per-point losses of the backbone heads, forward and gradients (the reference: GeneralModel._loss,
+ * model/general_model.py:36-50 -- cross_entropy(ignore_index=-1) -- and PTOffsetLoss, loss/pt_offset_loss.py:11-38 -- mean
+ * L1 norm of the offset error and mean negative cosine over the points with instance_ids != -1; with no valid point a
+ * loss is 0).  forward: out5 = (semantic loss, offset norm loss, offset direction loss, 1 / #labelled, 1 / #instance
+ * points); d_scores [N, C], d_norm / d_dir [N, 3] receive the UNNORMALISED gradients; partial_ws: 5 doubles per block of
+ * ms3d_point_losses_blocks(N).  scale_grads (backward): d_scores *= *g_sem * out5[3] in place and
+ * d_norm = (*g_norm * d_norm + *g_dir * d_dir) * out5[4]; g_* are DEVICE scalars (the upstream gradients) or NULL (= 0). */
+int ms3d_point_losses_blocks(long N);
+int ms3d_point_losses_forward(const float *scores /*[N,C]*/, const short *labels /*[N]*/, const float *pred_offsets /*[N,3]*/,
+                              const float *centre /*[N,3]*/, const float *xyz /*[N,3]*/, const short *instance_ids /*[N]*/,
+                              long N, int C, float *d_scores, float *d_norm, float *d_dir, double *partial_ws, float *out5,
+                              ms3d_stream_t stream);
+int ms3d_point_losses_scale_grads(float *d_scores, long n_scores, float *d_norm, const float *d_dir, long n_off,
+                                  const float *out5, const float *g_sem, const float *g_norm, const float *g_dir,
+                                  ms3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

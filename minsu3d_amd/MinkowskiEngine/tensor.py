@@ -70,11 +70,27 @@ class CoordinateManager:
     def identity(self, ts):
         if ts not in self._ident:
             V = self.coords[ts].size(0)
-            self._ident[ts] = torch.arange(V, dtype=torch.int32, device=self.coords[ts].device).view(1, V)
+            self._ident[ts] = _iota(V, self.coords[ts].device).view(1, V)
         return self._ident[ts]
 
     def size(self, ts):
         return self.coords[ts].size(0)
+
+
+_IOTA = {}
+
+
+def _iota(n, device):
+    """int32 0..n-1 as a view of one long, growing arange per device (the K = 1 tables of every level of every batch: 9
+    arange launches per step otherwise)"""
+    t = _IOTA.get(device)
+    if t is None or t.numel() < n:
+        t = _IOTA[device] = torch.arange(max(2 * n, 1 << 20), dtype=torch.int32, device=device)
+        if t.is_cuda:
+            # used from several streams (main, prefetch) without further ordering: complete before anybody sees it
+            # (happens once, and again only when a larger batch makes it grow)
+            torch.cuda.current_stream(device).synchronize()
+    return t[:n]
 
 
 _PREFETCHED = {}   # (data_ptr, shape) of a coordinate tensor -> (future of (manager, cuda event), the tensor itself)

@@ -352,6 +352,29 @@ class HipBackend:
                                                   _lib.ptr(dst), _lib.stream_handle()), "ms3d_scatter_add_rows")
         return dst
 
+    # ------------------------------------------------------------------ per-point losses
+    def point_losses_forward(self, scores, labels, pred_offsets, centre, xyz, instance_ids):
+        """-> (out5 device f32 [5] = three losses + the two 1/count factors, d_scores [N,C], d_norm [N,3], d_dir [N,3]
+        unnormalised gradients); see include/minsu3d_hip.h"""
+        N, Cc = scores.shape
+        dev = scores.device
+        assert labels.dtype == torch.int16 and instance_ids.dtype == torch.int16 and scores.dtype == torch.float32
+        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        d_scores = torch.empty_like(scores)
+        d_off = torch.empty((2, N, 3), dtype=torch.float32, device=dev)
+        ws = self.ws.get("ploss", 40 * self.lib.ms3d_point_losses_blocks(C.c_long(N)), dev)
+        _lib.check(self.lib.ms3d_point_losses_forward(
+            _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(pred_offsets), _lib.ptr(centre), _lib.ptr(xyz),
+            _lib.ptr(instance_ids), C.c_long(N), int(Cc), _lib.ptr(d_scores), _lib.ptr(d_off[0]), _lib.ptr(d_off[1]),
+            _lib.ptr(ws), _lib.ptr(out5), _lib.stream_handle()), "ms3d_point_losses_forward")
+        return out5, d_scores, d_off
+
+    def point_losses_scale_grads(self, d_scores, d_off, out5, g_sem, g_norm, g_dir):
+        _lib.check(self.lib.ms3d_point_losses_scale_grads(
+            _lib.ptr(d_scores), C.c_long(d_scores.numel()), _lib.ptr(d_off[0]), _lib.ptr(d_off[1]),
+            C.c_long(d_off[0].numel()), _lib.ptr(out5), _lib.ptr(g_sem), _lib.ptr(g_norm), _lib.ptr(g_dir),
+            _lib.stream_handle()), "ms3d_point_losses_scale_grads")
+
     # ------------------------------------------------------------------ IoU family
     def _iou(self, fn_name, prop_idx, prop_off, inst_labels, inst_pointnum, sigmoid=None):
         prop_idx = self._dev(prop_idx); prop_off = self._dev(prop_off)

@@ -80,6 +80,19 @@ class GeneralModel(nn.Module):
         return queued if queued is not None else self._point_losses(data_dict, output_dict)
 
     def _point_losses(self, data_dict, output_dict):
+        scores = output_dict["semantic_scores"]
+        if (scores.is_cuda and scores.dtype == torch.float32 and os.environ.get("MS3D_FUSED_LOSS", "1") != "0"
+                and data_dict["sem_labels"].dtype == torch.int16 and data_dict["instance_ids"].dtype == torch.int16
+                and hasattr(get_backend(), "point_losses_forward")):
+            # one autograd node, three launches (csrc/losses.hip) instead of ~70 torch operators forward + backward
+            from ..loss.point_losses import point_losses
+            sem, norm_l, dir_l = point_losses(scores, output_dict["point_offsets"], data_dict["sem_labels"],
+                                              data_dict["instance_center_xyz"], data_dict["point_xyz"],
+                                              data_dict["instance_ids"])
+            return {"semantic_loss": sem, "offset_norm_loss": norm_l, "offset_dir_loss": dir_l}
+        return GeneralModel._point_losses_torch(self, data_dict, output_dict)
+
+    def _point_losses_torch(self, data_dict, output_dict):
         # cross entropy with ignore_index = -1 (reference general_model.py:39-41), written as log-softmax + gather:
         # torch's fused nll_loss forward reduces 10^5..10^6 rows in a single block
         labels = data_dict["sem_labels"].long()

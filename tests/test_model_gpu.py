@@ -509,3 +509,45 @@ def test_deferred_slab_reduction_gives_the_same_gradients(monkeypatch):
             assert (twice[n] - 2 * want[n]).abs().max().item() <= 2e-4 * scale + 1e-12, n
     finally:
         be._wgrad_defer = None
+
+
+@pytest.mark.parametrize("n,C_,valid", [(50000, 20, 0.8), (777, 20, 0.5), (3000, 7, 0.0)])
+def test_fused_point_losses_match_the_torch_formulation(n, C_, valid):
+    """csrc/losses.hip (one autograd node, three launches) against GeneralModel._point_losses_torch -- itself pinned to the
+    reference's GeneralModel._loss / PTOffsetLoss by tests/golden/model_cases.npz: the three loss values and the gradients
+    w.r.t. the semantic scores and the offsets, with unequal upstream weights, ignored labels, points without an instance,
+    a zero prediction (the eps branch of the normalisation) and the no-valid-point case"""
+    from types import SimpleNamespace
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from minsu3d_amd.loss import PTOffsetLoss
+    from minsu3d_amd.model.general_model import GeneralModel
+    backend.set_backend(HipBackend())
+    g = torch.Generator().manual_seed(n)
+    labels = torch.randint(0, C_, (n,), generator=g).to(torch.int16)
+    labels[torch.rand(n, generator=g) > max(valid, 0.3)] = -1
+    inst = torch.randint(0, 9, (n,), generator=g).to(torch.int16)
+    inst[torch.rand(n, generator=g) >= valid] = -1
+    d = {"sem_labels": labels.cuda(), "instance_ids": inst.cuda(), "point_xyz": (torch.rand(n, 3, generator=g) * 4).cuda(),
+         "instance_center_xyz": (torch.rand(n, 3, generator=g) * 4).cuda()}
+    scores0 = (torch.randn(n, C_, generator=g) * 3).cuda()
+    offs0 = torch.randn(n, 3, generator=g).cuda()
+    offs0[5] = 0.0
+    offs0[6] = d["instance_center_xyz"][6] - d["point_xyz"][6]          # exact hit: sign(0) = 0
+    me = SimpleNamespace(offset_criterion=PTOffsetLoss())
+    w = (0.7, 1.3, 0.4)
+    res = []
+    for fused in (True, False):
+        scores, offs = scores0.clone().requires_grad_(True), offs0.clone().requires_grad_(True)
+        fn = GeneralModel._point_losses if fused else GeneralModel._point_losses_torch
+        losses = fn(me, d, {"semantic_scores": scores, "point_offsets": offs})
+        assert list(losses) == ["semantic_loss", "offset_norm_loss", "offset_dir_loss"]
+        sum(wi * li for wi, li in zip(w, losses.values())).backward()
+        res.append(([float(v.detach()) for v in losses.values()], scores.grad.clone(), offs.grad.clone()))
+    (lf, gsf, gof), (lt, gst, got_) = res
+    for a, b_ in zip(lf, lt):
+        assert abs(a - b_) <= 2e-6 * max(abs(b_), 1e-3), (lf, lt)
+    assert (gsf - gst).abs().max().item() <= 2e-6 * max(gst.abs().max().item(), 1e-12) + 1e-12
+    assert (gof - got_).abs().max().item() <= 2e-5 * max(got_.abs().max().item(), 1e-12) + 1e-12
+    if valid == 0.0:
+        assert lf[1] == 0.0 and lf[2] == 0.0 and float(gof.abs().max()) == 0.0
