@@ -107,11 +107,33 @@ def side_stream(device):
     return s
 
 
+def _load_host_ext():
+    """minsu3d_amd/lib/_ms3d_host.so (csrc_host/ms3d_host.cpp, built by build.build_host): the per-layer calls as one
+    pybind call each instead of ctypes marshalling.  None when it is not built or MS3D_HOST_EXT=0 -- ctypes then serves
+    every call (same library, same kernels)."""
+    if os.environ.get("MS3D_HOST_EXT", "1") == "0":
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_ms3d_host.so")
+    if not os.path.exists(path) or (os.environ.get("MS3D_LIB") and os.environ["MS3D_LIB"] != _lib.LIB_PATH):
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("_ms3d_host", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except (ImportError, OSError) as e:      # e.g. built against another torch: fall back, but say so once
+        import warnings
+        warnings.warn(f"minsu3d_amd: host extension {path} did not load ({e}); using the ctypes path")
+        return None
+
+
 class HipBackend:
     name = "hip"
 
     def __init__(self):
         self.lib = _lib.lib()  # raises HipLibraryError when the .so is absent
+        self.ext = _load_host_ext() if not os.environ.get("MS3D_LIB") else None
         self.ws = _Workspace()
         self.kernel_timer = None  # bench.py installs a KernelTimer to bracket chosen launches with HIP events
         self.weight_token = 0     # see prep_weights_multi
@@ -336,6 +358,8 @@ class HipBackend:
     def gather_rows(self, x, idx):
         """x[idx] for f32 [V, C] rows and an int64 index, at copy speed"""
         x = self._dev(x); idx = self._dev(idx)
+        if self.ext is not None:
+            return self.ext.gather_rows(x, idx)
         assert idx.dtype == torch.int64 and x.dtype == torch.float32 and x.dim() == 2
         x = x.contiguous(); idx = idx.contiguous()
         out = torch.empty((idx.numel(), x.size(1)), dtype=torch.float32, device=x.device)
@@ -831,16 +855,22 @@ class _HipEngine:
         x = self._dev(x)
         dev = x.device
         wf_buf = wf_ready if wf_ready is not None else torch.empty(self.wf_floats(K, cin, cout), dtype=torch.float32, device=dev)
-        y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
-        stats = None
         pl = self.pairlist(nbr_fwd, K, vout, cin, cout)
-        if want_stats:
-            nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, int(pl[0] is not None))
-            stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev)
+        nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, int(pl[0] is not None)) if want_stats else 0
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
         tok = timer.conv("fwd", K, cin, cout, nbr_fwd, vout) if timer is not None else None
         ev0, ev1 = tok if tok is not None else (None, None)
+        ext = self.ext
+        if ext is not None:
+            # one pybind call: outputs allocated and the C ABI entered from native code (csrc_host/ms3d_host.cpp)
+            y, stats = ext.conv_layer_forward(
+                x, None if wf_ready is not None else self._dev(W3), nbr_fwd, vout, K, cin, cout, bool(mirror_bwd),
+                _f32(ps), _f32(pb), bool(pre_relu), _f32(residual), _f32(bias), wf_buf, nparts, pl[0], pl[1],
+                (ev0.value or 0) if ev0 is not None else 0, (ev1.value or 0) if ev1 is not None else 0)
+            return y, stats, wf_buf
+        y = torch.empty((vout, cout), dtype=torch.float32, device=dev)
+        stats = torch.empty((nparts, 2, cout), dtype=torch.float32, device=dev) if want_stats else None
         _lib.check(self._fast("ms3d_spconv_layer_forward")(
             _p(x), _p(None if wf_ready is not None else self._dev(W3)), _p(nbr_fwd), int(vout), int(K), int(cin), int(cout),
             int(bool(mirror_bwd)), _p(_f32(ps)), _p(_f32(pb)), int(bool(pre_relu)), _p(_f32(residual)),
@@ -860,9 +890,6 @@ class _HipEngine:
         ws = self.ws.get("layer", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
         has_bn = bn is not None
         want_dx = need_dx or has_bn
-        dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
-        dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
-        dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
         plf = self.offsetlist(nbr_fwd, K, vout)
         plb = self.pairlist(nbr_bwd, K, vin, cout, cin) if want_dx else (None, None)
         timer = self.kernel_timer
@@ -871,6 +898,20 @@ class _HipEngine:
         tok = timer.conv("wgrad", K, cin, cout, nbr_fwd, vout) if timer is not None else None
         ev2, ev3 = tok if tok is not None else (None, None)
         mode = self.wgrad_stream_mode()
+        if self.ext is not None and mode == 0:
+            evs = [(e.value or 0) if e is not None else 0 for e in (ev0, ev1, ev2, ev3)]
+            dx, dgb, dW, slabs, nblk = self.ext.conv_layer_backward(
+                x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout,
+                bn["scale"] if has_bn else None, bn["shift"] if has_bn else None, bn["mean"] if has_bn else None,
+                bn["invstd"] if has_bn else None, bool(has_bn and bn["relu"]), bool(has_bn and bn["training"]), bool(need_dx),
+                _f32(dx_add) if (dx_add is not None and need_dx) else None, ws, plf[0], plf[1], plb[0], plb[1], *evs,
+                self._geom("ms3d_spconv_wgrad_ws_floats", vout, K, cin, cout) if defer is not None else 0)
+            if nblk > 0:
+                defer.add(slabs, dW, K * cin * cout, nblk)
+            return dx, dgb, dW
+        dx = torch.empty((vin, cin), dtype=torch.float32, device=dev) if want_dx else None
+        dgb = torch.empty((2, cin), dtype=torch.float32, device=dev) if has_bn else None
+        dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
         side = wgrad_stream(dev) if mode else None
         ws2 = None
         if side is not None:
@@ -970,6 +1011,8 @@ class _HipEngine:
 
     def bn_finalize(self, partial, V, eps, momentum, gamma, beta, running_mean, running_var):
         """statistics from the (sum, sum of squares) partials a conv epilogue left behind -> (mean, invstd, scale, shift)"""
+        if self.ext is not None:
+            return self.ext.bn_finalize(partial, V, eps, momentum, _f32(gamma), _f32(beta), running_mean, running_var).unbind(0)
         C_ = partial.size(2)
         outs = torch.empty((4, C_), dtype=torch.float32, device=partial.device)
         base, row = outs.data_ptr(), 4 * C_

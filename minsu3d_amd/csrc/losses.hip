@@ -107,19 +107,30 @@ __global__ __launch_bounds__(PL_THREADS) void point_losses_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void point_losses_finalize_kernel(const double *__restrict__ partial, int nblk,
-                                                                  float *__restrict__ out /* [5] */)
+__global__ __launch_bounds__(1024) void point_losses_finalize_kernel(const double *__restrict__ partial, int nblk,
+                                                                    float *__restrict__ out /* [5] */)
 {
-    // lane l sums blocks l, l + 64, ... ; the 64 lane sums are folded in a fixed order
+    // thread t sums blocks t, t + 1024, ...; lanes fold with shuffles, the 16 wave sums in wave order: fixed order
+    __shared__ double s_w[16][5];
     double s[5] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblk; b += 64)
+    for (int b = threadIdx.x; b < nblk; b += 1024)
 #pragma unroll
         for (int t = 0; t < 5; t++) s[t] += partial[5 * (size_t)b + t];
 #pragma unroll
     for (int t = 0; t < 5; t++)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s[t] += __shfl_xor(s[t], d, 64);
+    if (lane_id() == 0)
+#pragma unroll
+        for (int t = 0; t < 5; t++) s_w[wave_id()][t] = s[t];
+    __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            double a = 0.0;
+            for (int w = 0; w < 16; w++) a += s_w[w][t];
+            s[t] = a;
+        }
         const double nsem = s[1] > 1.0 ? s[1] : 1.0, noff = s[4] > 1.0 ? s[4] : 1.0;
         out[0] = (float)(s[0] / nsem);
         out[1] = (float)(s[2] / noff);
@@ -171,7 +182,7 @@ int ms3d_point_losses_forward(const float *scores, const short *labels, const fl
     point_losses_kernel<<<nblk, PL_THREADS, (size_t)PL_THREADS * (C | 1) * sizeof(float), (hipStream_t)stream>>>(
         scores, labels, pred_offsets, centre, xyz, instance_ids, N, C, d_scores, d_norm, d_dir, partial_ws);
     MS3D_LAUNCH_CHECK();
-    point_losses_finalize_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial_ws, nblk, out5);
+    point_losses_finalize_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partial_ws, nblk, out5);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
