@@ -47,3 +47,24 @@ def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.HipLibraryError):
         backend.HipBackend()
+
+
+def test_host_extensions_build_and_export_the_reference_surface():
+    """the PyTorch C++ extensions over the C ABI (built by __graft_entry__.build() with the host compiler): `COMMON_OPS`
+    exports exactly the 15 functions of the reference's pybind module (common_ops_api.cpp:6-30) and the engine fast path
+    its four entry points; loading them needs no GPU (no compute here)"""
+    import torch  # noqa: F401
+    from minsu3d_amd import build as hipbuild
+    import minsu3d_amd.dropin as dropin
+    hipbuild.build_host()
+    ops = dropin.load_extension()
+    want = {"sg_bfs_cluster", "global_avg_pool_fp", "global_avg_pool_bp", "ballquery_batch_p", "sec_mean", "sec_min",
+            "sec_max", "roipool_fp", "roipool_bp", "get_iou", "get_mask_iou_on_cluster", "get_mask_iou_on_pred",
+            "get_mask_label", "pg_bfs_cluster", "hierarchical_aggregation"}
+    assert {n for n in dir(ops) if not n.startswith("_")} == want
+    import minsu3d_amd.dropin.COMMON_OPS as shim
+    assert set(shim.__all__) == want                     # the ctypes form of the module offers the same names
+    from minsu3d_amd.backend import _load_host_ext
+    ext = _load_host_ext()
+    assert ext is not None and all(hasattr(ext, n) for n in ("conv_layer_forward", "conv_layer_backward", "bn_finalize",
+                                                               "gather_rows"))

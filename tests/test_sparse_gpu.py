@@ -568,7 +568,7 @@ def test_host_extension_and_ctypes_paths_agree(be, oracle, cin, cout, K):
         fin = b_.bn_finalize(stats, vout, 1e-5, 0.1, pre[0], pre[1], None, None)
         outs.append([y, stats, dx, dgb, dW, dx2, dW2, torch.stack(fin), b_.gather_rows(y, torch.arange(0, vout, 3, device="cuda"))])
     for i, (a, b2) in enumerate(zip(*outs)):
-        if i in (1, 3, 7):      # per-channel sums collected with LDS float atomics: the order differs from run to run
+        if i in (1, 2, 3, 7):   # per-channel sums collected with LDS float atomics (and the dx built from them): run-to-run noise
             assert torch.allclose(a, b2, rtol=1e-4, atol=1e-4 * float(b2.abs().max()))
         else:
             assert torch.equal(a, b2), i
