@@ -326,7 +326,15 @@ def main(argv=None):
     scene_kwargs = None if args.density == 1700.0 else {"density": args.density}
     if args.scene:
         scene_kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(args.scene).items()}
-    batches = [make_batch(shard_scene_seeds(s, args.batch, rank, world), device, scene_kwargs) for s in range(args.pool)]
+    seeds = [shard_scene_seeds(s, args.batch, rank, world) for s in range(args.pool)]
+    batches = [make_batch(sd, device, scene_kwargs) for sd in seeds]
+    rank_report = None
+    if dry and world > 1:
+        # dry run only: which scenes and which host cores every rank got (tests/test_bench_cpu.py checks them disjoint)
+        mine = {"rank": rank, "scene_ids": sorted(i for sd in seeds for i in sd),
+                "cores": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []}
+        rank_report = [None] * world
+        torch.distributed.all_gather_object(rank_report, mine)
     n_pts = float(np.mean([b["point_xyz"].shape[0] for b in batches])) / args.batch
     n_vox = float(np.mean([b["voxel_xyz"].shape[0] for b in batches])) / args.batch
 
@@ -411,6 +419,8 @@ def main(argv=None):
                           f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}", file=sys.stderr)
         if dry:
             line["dry_run"] = "host tensors over gloo: exercises the launch path only, the numbers mean nothing"
+            if rank_report is not None:
+                line["dry_run_ranks"] = rank_report
         if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(cfg, config1=args.cpu_config1)
         also = args.also

@@ -41,6 +41,36 @@ def test_driver_launch_line_on_gloo(world):
     assert rec["step_ms"]["min"] <= rec["step_ms"]["median"] <= rec["step_ms"]["max"]
 
 
+def test_eight_ranks_get_disjoint_scenes_and_cores():
+    """BASELINE config 4's process layout (8 ranks on one node, LOCAL_WORLD_SIZE = 8) on host processes over gloo: every
+    rank trains on its own scenes (no scene id twice) and -- when the container has the cores -- on its own core slice;
+    one JSON line, value = scenes of all 8 ranks / the slowest rank's time.  The launch line is the driver's."""
+    world = 8
+    tail = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--batch", "1", "--pool", "2", "--scene", SCENE,
+            "--override", "model.network.blocks=[1,2]"]
+    script = os.path.join(ROOT, "tests", "bench_dryrun.py")
+    port = 29600 + (os.getpid() + 61) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), script] + tail
+    env = dict(os.environ, OMP_NUM_THREADS="1", MS3D_DIST_BACKEND="gloo")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["parallelism"] == "dp8" and rec["scaling"] == "weak"
+    ranks = sorted(rec["dry_run_ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    ids = [i for r in ranks for i in r["scene_ids"]]
+    assert len(ids) == len(set(ids)) == 8 * 2                      # 8 ranks x pool of 2 one-scene batches, all different
+    allowed = len(os.sched_getaffinity(0))
+    if allowed >= 8:
+        cores = [set(r["cores"]) for r in ranks]
+        assert all(len(c) == allowed // 8 for c in cores)
+        assert all(a.isdisjoint(b) for i, a in enumerate(cores) for b in cores[i + 1:])
+    assert abs(rec["value"] - 8 * 1 * 1 / (rec["ms_per_step"] / 1000.0)) < 1e-2 * rec["value"]
+
+
 def test_ranks_get_disjoint_core_slices():
     """8 ranks x (main + helper + loader threads) + torch's intra-op pools must not fight for the same cores: each rank
     pins itself to its own slice of the cores the process may use (parallel.pin_rank_threads)"""
