@@ -240,7 +240,11 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
                                       f"(digest {t.get('kernel_source_digest')} != {kernel_source_digest()}): not reported")
     rows = []
     for k, v in groups.items():
-        if k[0].startswith("spconv_"):
+        if k[0].startswith("spconv_") and len(k) == 6:
+            _, K, cin, cout, nrows, nlayers = k
+            name = (f"{k[0]} [table-walk, BATCHED: {nlayers} layers of one kernel shape class in one launch] backward-weight, "
+                    f"first layer K={K} {cin}->{cout} rows={nrows}")
+        elif k[0].startswith("spconv_"):
             _, K, cin, cout, nrows = k
             kind = "forward/backward-data" if k[0] == "spconv_fwd" else "backward-weight"
             name = f"{k[0]} [{_conv_variant(k[0], K, cin, cout, nrows, lib)}] {kind} K={K} {cin}->{cout} rows={nrows}"

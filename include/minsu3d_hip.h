@@ -314,7 +314,19 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                int *wgrad_deferred_nblk /* [host] NULL, or (with wgrad_slabs): the slab reduction is NOT
                                                            launched; receives the number of slabs to reduce later with
                                                            ms3d_wgrad_reduce_multi (0: dW is final) */,
+                               void *wgrad_deferred_launch /* [host] NULL, or (with the two above, no timing events) a buffer of
+                                                              ms3d_spconv_wgrad_launch_bytes(): when the layer's backward-weight
+                                                              takes the f32 table walk (the small levels) the KERNEL is not
+                                                              launched either but described here; int[4] of the buffer =
+                                                              variant (0: it was launched as usual), int[1..3] = its grid */,
                                ms3d_stream_t stream);
+/* Deferred backward-weight launches of MANY layers of one variant as one launch: descs = DEVICE array of the 128-byte
+ * descriptions, each with its first int set to the layer's first block (blocks are numbered layer after layer, a layer
+ * has int[1] * int[2] * int[3] of them), total_blocks = their sum.  x, dy, the tables and the slab areas the descriptions
+ * point to must still be alive.  Follow with ms3d_wgrad_reduce_multi over the same layers. */
+size_t ms3d_spconv_wgrad_launch_bytes(void);
+int ms3d_spconv_wgrad_is_table_walk(int Vout, int K, int Cin, int Cout, int offset_list);
+int ms3d_spconv_wgrad_multi(const void *descs, int n_desc, int total_blocks, int variant, ms3d_stream_t stream);
 /* The slab reductions dW = sum of slabs of MANY layers in one launch, bit-identical to the per-layer reduction.
  * descs: DEVICE array of n_desc records {const float *slabs; float *dW; int64_t n (floats per slab); int32_t nblk (slabs);
  * int32_t block_begin} (32 bytes each) in ascending block order; a layer takes ms3d_wgrad_reduce_blocks() blocks and sets

@@ -1769,12 +1769,11 @@ struct WgradArgs {
 // dimension (4 per instruction).  All KG neighbour indices, then all KG gathers, are issued before the first
 // MFMA so a wave keeps ~KG loads in flight; the KG offsets share the dout fragment.
 template <int KG, int NBT>
-__global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
+__device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, const int by, const int bz, float *s_red)
 {
-    __shared__ float s_red[4 * NBT * 256];  // every wave parks the NBT accumulators of one offset (4 regs x 64 lanes each)
     const int l = lane_id(), q = l >> 4, cl = l & 15;
-    const int k0 = blockIdx.y * KG;
-    const int c = blockIdx.z * 16 + cl;  // input channel owned by this lane's A element
+    const int k0 = by * KG;
+    const int c = bz * 16 + cl;  // input channel owned by this lane's A element
     const bool c_ok = c < p.Cin;
     const int c_safe = c_ok ? c : 0;
     const int c_mask = c_ok ? -1 : 0;
@@ -1786,7 +1785,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
 #pragma unroll
         for (int b = 0; b < NBT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int r_begin = blockIdx.x * p.rows_per_block;
+    const int r_begin = bx * p.rows_per_block;
     const int r_end = min(p.Vout, r_begin + p.rows_per_block);
     const int nw = blockDim.x >> 6;
     // Two independent 4-row steps per trip (rows r0.. and r0 + 4*nw..): all loads of both steps are issued before
@@ -1840,7 +1839,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
     // D layout: row (= input channel within the chunk) = 4q + reg, col (= output column) = cl.
     // Cross-wave sum through LDS, one offset (NBT accumulators) per barrier pair, all threads take part in the sum;
     // fixed wave order -> deterministic.  One plain store per element per block.
-    float *dst = p.partial + (size_t)blockIdx.x * p.K * p.Cin * p.Cout;
+    float *dst = p.partial + (size_t)bx * p.K * p.Cin * p.Cout;
 #pragma unroll
     for (int kk = 0; kk < KG; kk++) {
         const int k = k0 + kk;
@@ -1854,10 +1853,47 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
             float v = 0.f;
             for (int w = 0; w < nw; w++) v += s_red[w * NBT * 256 + e];
             const int nb = e >> 8, r = (e >> 6) & 3, ln = e & 63;
-            const int ci = blockIdx.z * 16 + 4 * (ln >> 4) + r, j = 16 * nb + (ln & 15);
+            const int ci = bz * 16 + 4 * (ln >> 4) + r, j = 16 * nb + (ln & 15);
             if (k < p.K && ci < p.Cin && j < p.Cout) dst[((size_t)k * p.Cin + ci) * p.Cout + j] = v;
         }
     }
+}
+
+template <int KG, int NBT>
+__global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradArgs p)
+{
+    __shared__ float s_red[4 * NBT * 256];  // every wave parks the NBT accumulators of one offset (4 regs x 64 lanes each)
+    wgrad_body<KG, NBT>(p, blockIdx.x, blockIdx.y, blockIdx.z, s_red);
+}
+
+// The same kernel for MANY layers in one launch (ms3d_spconv_wgrad_multi): the backward-weight of a layer needs its
+// input and its output gradient only, nothing downstream waits for it but the optimizer -- so the launches of the small
+// levels at the bottom of the U-Net (a few hundred to a few thousand rows: 25-40 us each, most of it launch floor, with
+// a fraction of the chip busy) are queued during the backward pass and run together, all layers of one (KG, NBT) shape
+// class side by side.  A block finds its layer in the descriptor table (blocks are numbered layer after layer).
+struct WgradLaunch {
+    int block_begin;   // first block of this layer in the batched launch (patched by the host when the table is built)
+    int gx, gy, gz;    // the layer's own grid
+    int variant;       // KG * 100 + NBT
+    int nblk;          // slabs it leaves in p.partial
+    int pad[2];
+    WgradArgs p;
+};
+static_assert(sizeof(WgradLaunch) <= 128, "ms3d_spconv_wgrad_launch_bytes() promises 128");
+
+template <int KG, int NBT>
+__global__ __launch_bounds__(256) void spconv_wgrad_multi_kernel(const unsigned char *__restrict__ descs, int n_desc)
+{
+    __shared__ float s_red[4 * NBT * 256];
+    int lo = 0, hi = n_desc - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {        // last descriptor whose first block is <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if (reinterpret_cast<const WgradLaunch *>(descs + 128 * (size_t)mid)->block_begin <= blk) lo = mid; else hi = mid - 1;
+    }
+    const WgradLaunch d = *reinterpret_cast<const WgradLaunch *>(descs + 128 * (size_t)lo);
+    const int local = blk - d.block_begin;
+    wgrad_body<KG, NBT>(d.p, local % d.gx, (local / d.gx) % d.gy, local / (d.gx * d.gy), s_red);
 }
 
 // ---- backward-weight on three-piece bf16 operands (wide submanifold layers) --------------------------------------
@@ -2224,10 +2260,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradRedu
 }
 
 template <int KG, int NBT>
-int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream)
+int launch_wgrad(const WgradArgs &p, int nblk_rows, hipStream_t stream, WgradLaunch *defer = nullptr)
 {
     dim3 grid(nblk_rows, ms3d_divup(p.K, KG), ms3d_divup(p.Cin, 16));
+    if (defer) {     // not launched: described for a later batched launch
+        defer->block_begin = 0;
+        defer->gx = grid.x; defer->gy = grid.y; defer->gz = grid.z;
+        defer->variant = KG * 100 + NBT;
+        defer->nblk = nblk_rows;
+        defer->p = p;
+        return 0;
+    }
     spconv_wgrad_kernel<KG, NBT><<<grid, 256, 0, stream>>>(p);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KG, int NBT>
+int launch_wgrad_multi(const void *descs, int n_desc, int total_blocks, hipStream_t stream)
+{
+    spconv_wgrad_multi_kernel<KG, NBT><<<total_blocks, 256, 0, stream>>>(static_cast<const unsigned char *>(descs), n_desc);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -3149,6 +3201,13 @@ static bool wgrad_bf3_ok(int Vout, int K, int Cin, int Cout, bool use_list)
     return bf3_enabled() && wg && !use_list && K == 27 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin % 16 == 0 && Cout % 16 == 0;
 }
 int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_list) { return wgrad_bf3_ok(Vout, K, Cin, Cout, offset_list != 0) ? 1 : 0; }
+// 1 when a backward-weight call of this shape takes the f32 table walk -- the kernel ms3d_spconv_layer_backward can leave
+// to a batched launch (offset_list: an offset list of the table is passed)
+int ms3d_spconv_wgrad_is_table_walk(int Vout, int K, int Cin, int Cout, int offset_list)
+{
+    const bool use_list = offset_list && ms3d_divup(Cout, 16) <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
+    return (Vout > 0 && !use_list && !wgrad_bf3_ok(Vout, K, Cin, Cout, use_list) && ms3d_divup(Cout, 16) <= 14) ? 1 : 0;
+}
 // slabs + (bf16x3 kernel) the dout operand image and the activated input pieces
 size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout)
 {
@@ -3177,7 +3236,7 @@ int ms3d_spconv_wgrad_row_chunks(int Vout)
 static int spconv_backward_weight_impl(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                        float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                        float *partial_ws, const int *ol_kt_start, const int *ol_entries, int *defer_nblk,
-                                       ms3d_stream_t stream_);
+                                       ms3d_stream_t stream_, void *defer_launch = nullptr);
 
 int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                 float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
@@ -3190,11 +3249,16 @@ int ms3d_spconv_backward_weight(const float *in, const float *dout, const int *n
 static int spconv_backward_weight_impl(const float *in, const float *dout, const int *nbr, int Vout, int K, int Cin, int Cout,
                                        float *dW, const float *pre_scale, const float *pre_shift, int pre_relu,
                                        float *partial_ws, const int *ol_kt_start, const int *ol_entries, int *defer_nblk,
-                                       ms3d_stream_t stream_)
+                                       ms3d_stream_t stream_, void *defer_launch)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const long n = (long)K * Cin * Cout;
     if (defer_nblk) *defer_nblk = 0;
+    // defer_launch (a host buffer of ms3d_spconv_wgrad_launch_bytes(), only together with defer_nblk): when this call
+    // takes the f32 table walk, the kernel is NOT launched either -- the buffer describes it for ms3d_spconv_wgrad_multi;
+    // variant 0 = launched here as usual
+    WgradLaunch *dl = defer_nblk ? static_cast<WgradLaunch *>(defer_launch) : nullptr;
+    if (dl) dl->variant = 0;
     if (Vout <= 0) {
         MS3D_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * n, stream));
         return 0;
@@ -3296,17 +3360,17 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
         return 0;
     }
     // KG * NBT <= 28 accumulators of 4 VGPRs
-    if (nb == 1) rc = (K >= 27) ? launch_wgrad<9, 1>(p, nblk, stream) : launch_wgrad<8, 1>(p, nblk, stream);
-    else if (nb == 2) rc = (K >= 27) ? launch_wgrad<9, 2>(p, nblk, stream) : launch_wgrad<8, 2>(p, nblk, stream);
-    else if (nb == 3) rc = (K >= 27) ? launch_wgrad<9, 3>(p, nblk, stream) : launch_wgrad<8, 3>(p, nblk, stream);
-    else if (nb == 4) rc = launch_wgrad<4, 4>(p, nblk, stream);
-    else if (nb == 5) rc = launch_wgrad<4, 5>(p, nblk, stream);
-    else if (nb == 6) rc = launch_wgrad<4, 6>(p, nblk, stream);
-    else if (nb == 7) rc = launch_wgrad<4, 7>(p, nblk, stream);
-    else if (nb == 8) rc = launch_wgrad<3, 8>(p, nblk, stream);
-    else if (nb <= 10) rc = launch_wgrad<2, 10>(p, nblk, stream);
-    else if (nb <= 12) rc = launch_wgrad<2, 12>(p, nblk, stream);
-    else rc = launch_wgrad<2, 14>(p, nblk, stream);
+    if (nb == 1) rc = (K >= 27) ? launch_wgrad<9, 1>(p, nblk, stream, dl) : launch_wgrad<8, 1>(p, nblk, stream, dl);
+    else if (nb == 2) rc = (K >= 27) ? launch_wgrad<9, 2>(p, nblk, stream, dl) : launch_wgrad<8, 2>(p, nblk, stream, dl);
+    else if (nb == 3) rc = (K >= 27) ? launch_wgrad<9, 3>(p, nblk, stream, dl) : launch_wgrad<8, 3>(p, nblk, stream, dl);
+    else if (nb == 4) rc = launch_wgrad<4, 4>(p, nblk, stream, dl);
+    else if (nb == 5) rc = launch_wgrad<4, 5>(p, nblk, stream, dl);
+    else if (nb == 6) rc = launch_wgrad<4, 6>(p, nblk, stream, dl);
+    else if (nb == 7) rc = launch_wgrad<4, 7>(p, nblk, stream, dl);
+    else if (nb == 8) rc = launch_wgrad<3, 8>(p, nblk, stream, dl);
+    else if (nb <= 10) rc = launch_wgrad<2, 10>(p, nblk, stream, dl);
+    else if (nb <= 12) rc = launch_wgrad<2, 12>(p, nblk, stream, dl);
+    else rc = launch_wgrad<2, 14>(p, nblk, stream, dl);
     if (rc) return rc;
     if (defer_nblk) { *defer_nblk = nblk; return 0; }
     launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
@@ -3317,6 +3381,23 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
 // slab reductions of many layers in one launch.  descs (DEVICE memory): n_desc records of 32 bytes
 // {const float *slabs; float *dW; int64 n; int32 nblk; int32 block_begin | geometry bit} in ascending block order,
 // block counts from ms3d_wgrad_reduce_blocks (which also tells the geometry bit)
+size_t ms3d_spconv_wgrad_launch_bytes(void) { return 128; }
+
+// descs: DEVICE array of n_desc 128-byte launch descriptions of ONE variant (what ms3d_spconv_layer_backward wrote into
+// wgrad_deferred_launch, the first int of each patched to the layer's first block), total_blocks = sum of gx*gy*gz
+int ms3d_spconv_wgrad_multi(const void *descs, int n_desc, int total_blocks, int variant, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_desc <= 0 || total_blocks <= 0) return 0;
+    switch (variant) {
+#define MS3D_WM(KG, NBT) case KG * 100 + NBT: return launch_wgrad_multi<KG, NBT>(descs, n_desc, total_blocks, stream);
+        MS3D_WM(9, 1) MS3D_WM(8, 1) MS3D_WM(9, 2) MS3D_WM(8, 2) MS3D_WM(9, 3) MS3D_WM(8, 3) MS3D_WM(4, 4) MS3D_WM(4, 5)
+        MS3D_WM(4, 6) MS3D_WM(4, 7) MS3D_WM(3, 8) MS3D_WM(2, 10) MS3D_WM(2, 12) MS3D_WM(2, 14)
+#undef MS3D_WM
+    }
+    return MS3D_E_UNSUPPORTED;
+}
+
 int ms3d_wgrad_reduce_blocks(long n, const float *slabs, const float *dW, int *wide)
 {
     const bool w = n >= 32768 && (n & 3) == 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dW & 15) == 0;
@@ -3508,7 +3589,7 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
                                const int *ol_fwd_kt_start, const int *ol_fwd_entries, const int *pl_bwd_tile_start,
                                const int *pl_bwd_entries, void *ev_start, void *ev_stop, void *ev_wg_start, void *ev_wg_stop,
                                float *ws_wgrad, ms3d_stream_t wgrad_stream, int join, float *wgrad_slabs,
-                               int *wgrad_deferred_nblk, ms3d_stream_t stream)
+                               int *wgrad_deferred_nblk, void *wgrad_deferred_launch, ms3d_stream_t stream)
 {
     const size_t nwf = ms3d_spconv_wf_floats(K, Cin, Cout);
     const float *wft = wf_buf + 3 * nwf, *wfts = wf_buf + 4 * nwf;
@@ -3527,7 +3608,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
         // left to one ms3d_wgrad_reduce_multi launch over many layers
         int r = spconv_backward_weight_impl(x, dy, nbr_fwd, Vout, K, Cin, Cout, dW, scale, shift, pre_relu,
                                             wgrad_slabs ? wgrad_slabs : slabs, ol_fwd_kt_start, ol_fwd_entries,
-                                            wgrad_slabs ? wgrad_deferred_nblk : nullptr, (ms3d_stream_t)side);
+                                            wgrad_slabs ? wgrad_deferred_nblk : nullptr, (ms3d_stream_t)side,
+                                            (wgrad_slabs && !ev_wg_start) ? wgrad_deferred_launch : nullptr);
         if (ev_wg_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_wg_stop, side));
         return r;
     };

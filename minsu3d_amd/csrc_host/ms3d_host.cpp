@@ -58,14 +58,16 @@ std::tuple<at::Tensor, OptT> conv_layer_forward(const at::Tensor &x, const OptT 
     return {y, stats};
 }
 
-// -> (dx or None, dgb [2, cin] or None, dW [K, cin, cout], slabs or None, slabs to reduce later).  defer_floats > 0: the
-// backward-weight slabs go into a fresh tensor of that many floats and are NOT reduced (backend.WgradQueue does it).
-std::tuple<OptT, OptT, at::Tensor, OptT, int64_t> conv_layer_backward(
+// -> (dx or None, dgb [2, cin] or None, dW [K, cin, cout], slabs or None, slabs to reduce later, launch description).
+// defer_floats > 0: the backward-weight slabs go into a fresh tensor of that many floats and are NOT reduced
+// (backend.WgradQueue does it); defer_launch: a layer on the f32 table walk does not launch its backward-weight kernel
+// either, the 128-byte description comes back instead (empty bytes: it was launched).
+std::tuple<OptT, OptT, at::Tensor, OptT, int64_t, py::bytes> conv_layer_backward(
     const at::Tensor &x, const at::Tensor &dy, const at::Tensor &wf_buf, const at::Tensor &nbr_fwd, const at::Tensor &nbr_bwd,
     int64_t vin, int64_t vout, int64_t K, int64_t cin, int64_t cout, const OptT &scale, const OptT &shift, const OptT &mean,
     const OptT &invstd, bool relu, bool training, bool need_dx, const OptT &dx_add, at::Tensor ws, const OptT &ol_kt_start,
     const OptT &ol_entries, const OptT &pl_tile_start, const OptT &pl_entries, int64_t ev0, int64_t ev1, int64_t ev2,
-    int64_t ev3, int64_t defer_floats)
+    int64_t ev3, int64_t defer_floats, bool defer_launch)
 {
     TORCH_CHECK(x.is_cuda() && x.is_contiguous() && dy.is_contiguous(), "x / dy: contiguous device tensors");
     const bool has_bn = scale.has_value() && scale->defined();
@@ -74,6 +76,8 @@ std::tuple<OptT, OptT, at::Tensor, OptT, int64_t> conv_layer_backward(
     if (has_bn) dgb = at::empty({2, cin}, x.options());
     at::Tensor dW = at::empty({K, cin, cout}, x.options());
     int nblk = 0;
+    alignas(16) unsigned char launch[128];
+    reinterpret_cast<int *>(launch)[4] = 0;
     if (defer_floats > 0) slabs = at::empty({defer_floats}, x.options());
     check(ms3d_spconv_layer_backward(
               x.data_ptr<float>(), dy.data_ptr<float>(), wf_buf.data_ptr<float>(), nbr_fwd.data_ptr<int>(),
@@ -83,10 +87,11 @@ std::tuple<OptT, OptT, at::Tensor, OptT, int64_t> conv_layer_backward(
               dgb.has_value() ? dgb->data_ptr<float>() : nullptr, dW.data_ptr<float>(), (float *)ws.data_ptr(), iptr(ol_kt_start),
               iptr(ol_entries), iptr(pl_tile_start), iptr(pl_entries), (void *)ev0, (void *)ev1, (void *)ev2, (void *)ev3,
               nullptr, nullptr, 0, slabs.has_value() ? slabs->data_ptr<float>() : nullptr,
-              slabs.has_value() ? &nblk : nullptr, cur()),
+              slabs.has_value() ? &nblk : nullptr, (slabs.has_value() && defer_launch) ? (void *)launch : nullptr, cur()),
           "ms3d_spconv_layer_backward");
     if (!need_dx) dx = c10::nullopt;
-    return {dx, dgb, dW, slabs, (int64_t)nblk};
+    const bool described = reinterpret_cast<int *>(launch)[4] != 0;
+    return {dx, dgb, dW, slabs, (int64_t)nblk, py::bytes(reinterpret_cast<const char *>(launch), described ? 128 : 0)};
 }
 
 // batch statistics from a convolution epilogue's partials -> [4, C] = (mean, invstd, scale, shift); running stats updated

@@ -572,3 +572,42 @@ def test_host_extension_and_ctypes_paths_agree(be, oracle, cin, cout, K):
             assert torch.allclose(a, b2, rtol=1e-4, atol=1e-4 * float(b2.abs().max()))
         else:
             assert torch.equal(a, b2), i
+
+
+def test_batched_backward_weight_launch_is_bit_identical(be, oracle):
+    """the backward-weight kernels of small-level layers (f32 table walk) queued and run as ONE launch per kernel shape
+    class (ms3d_spconv_wgrad_multi) + one slab reduction (ms3d_wgrad_reduce_multi): bit-identical to the per-layer
+    launches, for layers of different shapes and tables in the same queue, through the extension and through ctypes"""
+    from minsu3d_amd.backend import HipBackend, WgradQueue
+    rng = np.random.default_rng(5)
+    plain = HipBackend()
+    plain.ext = None
+    layers = []
+    for cin, cout, K, npts in ((80, 80, 27, 2500), (80, 80, 27, 2500), (96, 96, 27, 600), (80, 96, 8, 2500), (112, 112, 27, 150),
+                               (64, 64, 27, 9000)):
+        c = surface_coords(rng, 2, npts, 40)
+        V = c.shape[0]
+        if K == 27:
+            nbr = oracle.kmap_k3(c, 1); nbr_bwd, vin, vout = nbr, V, V
+        else:
+            oc, par, ko = oracle.downsample(c, 1)
+            nbr, nbr_bwd = oracle.kmap_k2(par, ko, oc.shape[0]); vin, vout = V, oc.shape[0]
+        x = dev(rng.standard_normal((vin, cin)).astype(np.float32))
+        W = dev((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * K)).astype(np.float32))
+        g = dev(rng.standard_normal((vout, cout)).astype(np.float32))
+        pre = (dev(rng.uniform(0.5, 1.5, cin).astype(np.float32)), dev(rng.uniform(-0.5, 0.5, cin).astype(np.float32)))
+        bn = dict(scale=pre[0], shift=pre[1], mean=x.mean(0).contiguous(), invstd=torch.rsqrt(x.var(0) + 1e-5).contiguous(),
+                  relu=True, training=True)
+        layers.append((x, W, g, dev(nbr.T.copy()), dev(nbr_bwd.T.copy()), vin, vout, K, cin, cout, K == 27, bn))
+    for b_ in (be, plain):
+        want, got = [], []
+        queue = WgradQueue(b_.lib)
+        for x, W, g, nf, nb_, vin, vout, K, cin, cout, mirror, bn in layers:
+            _, _, wf = b_.conv_layer_forward(x, W, nf, vout, K, cin, cout, mirror, None, False, None, None, False)
+            want.append(b_.conv_layer_backward(x, g, wf, nf, nb_, vin, vout, K, cin, cout, bn, True)[2])
+            got.append(b_.conv_layer_backward(x, g, wf, nf, nb_, vin, vout, K, cin, cout, bn, True, defer=queue)[2])
+        assert len(queue.launches) >= 5 and len({l[0] for l in queue.launches}) >= 3      # several shape classes queued
+        queue.flush()
+        assert not queue.launches and not queue.items
+        for i, (a, b2) in enumerate(zip(got, want)):
+            assert torch.equal(a, b2), i
