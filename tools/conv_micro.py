@@ -6,6 +6,11 @@ import bench
 from minsu3d_amd import backend as B
 from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
 
+# K = 8u: the one-hot `up` table of a stride-2 map (transposed convolution forward, strided convolution backward-data):
+# output = the FINE rows of `level`, input = the coarse rows of level + 1
+UP = len(sys.argv) > 3 and sys.argv[3] == "8u"
+if UP:
+    sys.argv[3] = "8"
 cin, cout, K, level = (int(a) for a in (sys.argv[1:5] + ["16", "16", "27", "0"][len(sys.argv) - 1:]))
 dev = torch.device("cuda", 0)
 be = B.get_backend()
@@ -16,6 +21,8 @@ for _ in range(level):
     cm.k2(ts); ts *= 2
 if K == 27:
     nbr = cm.k3(ts); vin = vout = cm.size(ts)
+elif UP:
+    _, nbr = cm.k2(ts); vin, vout = cm.size(2 * ts), cm.size(ts)
 else:
     nbr, _ = cm.k2(ts); vin, vout = cm.size(ts), cm.size(2 * ts)
 pairs = int((nbr >= 0).sum())
