@@ -558,9 +558,6 @@ class WgradQueue:
     _host = _host_np = _dev = None      # descriptor staging, shared by all queues of the process (one device per process)
     _turn = 0
     RING = 16                           # pinned staging slots: a slot is rewritten 16 flushes (~4 steps) later
-    _lhost = _lhost_np = _ldev = None   # the same for the batched-launch tables (several variants per flush)
-    _lturn = 0
-    LRING = 64
 
     def __init__(self, lib, timer=None):
         self.lib = lib
@@ -577,68 +574,61 @@ class WgradQueue:
         head = np.frombuffer(desc, dtype=np.int32, count=6)
         self.launches.append((int(head[4]), desc, int(head[1]) * int(head[2]) * int(head[3]), keep, timing))
 
-    def _flush_launches(self, dev):
+    def flush(self):
+        """ONE staging table and ONE host->device copy per flush: [launch descriptions, 128 bytes each, grouped by kernel
+        shape class | reduction descriptions, 32 bytes each], then one launch per shape class and one reduction launch"""
         launches, self.launches = self.launches, []
+        items, self.items = self.items, []
+        if not launches and not items:
+            return
+        dev = (launches[0][3][0] if launches else items[0][1]).device
         by_variant = {}
         for l in launches:
             by_variant.setdefault(l[0], []).append(l)
-        for variant, group in by_variant.items():
-            cls = WgradQueue
-            if cls._lhost is None or cls._lhost[0].shape[0] < len(group) or cls._ldev[0].device != dev:
-                cap = max(2 * len(group), 64)
-                cls._lhost = [torch.empty((cap, 32), dtype=torch.int32).pin_memory() for _ in range(self.LRING)]
-                cls._lhost_np = [h.numpy() for h in cls._lhost]
-                cls._ldev = [torch.empty((cap, 32), dtype=torch.int32, device=dev) for _ in range(self.LRING)]
-            turn = cls._lturn
-            cls._lturn = (turn + 1) % self.LRING
-            table = cls._lhost_np[turn]
-            begin = 0
-            for i, (_, desc, blocks, _, _) in enumerate(group):
-                table[i] = np.frombuffer(desc, dtype=np.int32, count=32)
-                table[i, 0] = begin
-                begin += blocks
-            tdev = cls._ldev[turn]
-            tdev[:len(group)].copy_(cls._lhost[turn][:len(group)], non_blocking=True)
-            timing = [g[4] for g in group if g[4] is not None]
-            ev = self.timer.conv_group("wgrad", timing) if (self.timer is not None and timing) else None
-            if ev is not None:
-                self.lib.ms3d_event_record(ev[0], _lib.stream_handle())
-            _lib.check(self.lib.ms3d_spconv_wgrad_multi(_lib.ptr(tdev), len(group), int(begin), int(variant),
-                                                        _lib.stream_handle()), "ms3d_spconv_wgrad_multi")
-            if ev is not None:
-                self.lib.ms3d_event_record(ev[1], _lib.stream_handle())
-        return launches       # kept alive by the caller until the reductions are queued behind them
-
-    def flush(self):
-        alive = None
-        if self.launches:
-            alive = self._flush_launches(self.launches[0][3][0].device)
-        items, self.items = self.items, []
-        if not items:
-            return
-        m = len(items)
-        dev = items[0][1].device
+        rows = 4 * len(launches) + len(items)            # in 32-byte rows
         cls = WgradQueue
-        if cls._host is None or cls._host[0].shape[0] < m or cls._dev[0].device != dev:
-            cap = max(2 * m, 128)
+        if cls._host is None or cls._host[0].shape[0] < rows or cls._dev[0].device != dev:
+            cap = max(2 * rows, 512)
             cls._host = [torch.empty((cap, 4), dtype=torch.int64).pin_memory() for _ in range(self.RING)]
             cls._host_np = [h.numpy().view(np.uint64) for h in cls._host]
             cls._dev = [torch.empty((cap, 4), dtype=torch.int64, device=dev) for _ in range(self.RING)]
         turn = cls._turn
         cls._turn = (turn + 1) % self.RING
-        hn = cls._host_np[turn]
-        begin = 0
+        hn, tdev = cls._host_np[turn], cls._dev[turn]
+        h32 = hn.view(np.int32).reshape(-1, 32)          # the same bytes as 128-byte rows
+        plan, row = [], 0
+        for variant, group in by_variant.items():
+            begin = 0
+            for i, (_, desc, blocks, _, _) in enumerate(group):
+                h32[row + i] = np.frombuffer(desc, dtype=np.int32, count=32)
+                h32[row + i, 0] = begin
+                begin += blocks
+            plan.append((variant, row, len(group), begin, [g[4] for g in group if g[4] is not None]))
+            row += len(group)
+        r0 = 4 * row
+        begin_r = 0
         for i, (slabs, dW, n, nblk) in enumerate(items):
             ps, pw = slabs.data_ptr(), dW.data_ptr()
             wide = n >= 32768 and (n & 3) == 0 and (ps & 15) == 0 and (pw & 15) == 0   # ms3d_wgrad_reduce_blocks
             blocks = -(-(n // 4) // 64) if wide else -(-n // 16)
-            hn[i, 0], hn[i, 1], hn[i, 2] = ps, pw, n
-            hn[i, 3] = (nblk & 0xffffffff) | (((begin | (0x80000000 if wide else 0)) & 0xffffffff) << 32)
-            begin += blocks
-        cls._dev[turn][:m].copy_(cls._host[turn][:m], non_blocking=True)
-        _lib.check(self.lib.ms3d_wgrad_reduce_multi(_lib.ptr(cls._dev[turn]), m, int(begin), _lib.stream_handle()),
-                   "ms3d_wgrad_reduce_multi")
-        # `items` (the slab tensors) die here: the caching allocator reuses them stream-ordered, behind the launch
+            hn[r0 + i, 0], hn[r0 + i, 1], hn[r0 + i, 2] = ps, pw, n
+            hn[r0 + i, 3] = (nblk & 0xffffffff) | (((begin_r | (0x80000000 if wide else 0)) & 0xffffffff) << 32)
+            begin_r += blocks
+        tdev[:rows].copy_(cls._host[turn][:rows], non_blocking=True)
+        base = tdev.data_ptr()
+        for variant, first, n_desc, total, timing in plan:
+            ev = self.timer.conv_group("wgrad", timing) if (self.timer is not None and timing) else None
+            if ev is not None:
+                self.lib.ms3d_event_record(ev[0], _lib.stream_handle())
+            _lib.check(self.lib.ms3d_spconv_wgrad_multi(C.c_void_p(base + 128 * first), n_desc, int(total), int(variant),
+                                                        _lib.stream_handle()), "ms3d_spconv_wgrad_multi")
+            if ev is not None:
+                self.lib.ms3d_event_record(ev[1], _lib.stream_handle())
+        if items:
+            _lib.check(self.lib.ms3d_wgrad_reduce_multi(C.c_void_p(base + 32 * r0), len(items), int(begin_r),
+                                                        _lib.stream_handle()), "ms3d_wgrad_reduce_multi")
+        # `launches` / `items` (x, dy, the slab tensors) die here: the caching allocator reuses them stream-ordered,
+        # behind the launches
 
 
 class _HipEngine:
