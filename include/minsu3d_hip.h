@@ -388,6 +388,12 @@ int ms3d_adam_step_multi(const int *chunks, int n_chunks, void *const *p_ptrs, c
                          void *const *m_ptrs, void *const *v_ptrs, const long *sizes, const float *coef, float beta1,
                          float beta2, float eps, float weight_decay, ms3d_stream_t stream);
 
+/* ---- device-wide exclusive prefix sum of int32 (the utility behind the ball query's cell / list starts, the clustering
+ * output assembly and the coordinate engine): out[i] = in[0] + .. + in[i-1], in == out allowed, *total_out_dev (device,
+ * optional) = the sum of all.  One launch (decoupled look-back between workgroups).  workspace: ms3d_scan_i32_workspace_bytes(). */
+size_t ms3d_scan_i32_workspace_bytes(void);
+int ms3d_scan_i32(const int *in, int *out, int n, int *total_out_dev, void *workspace, ms3d_stream_t stream);
+
 /* ---- per-point losses of the backbone heads, forward and gradients (the reference: GeneralModel._loss,
  * model/general_model.py:36-50 -- cross_entropy(ignore_index=-1) -- and PTOffsetLoss, loss/pt_offset_loss.py:11-38 -- mean
  * L1 norm of the offset error and mean negative cosine over the points with instance_ids != -1; with no valid point a

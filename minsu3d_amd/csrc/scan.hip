@@ -1,6 +1,14 @@
-// Device-wide exclusive prefix sum of int32 (three short launches: per-span scan, span-sum
-// scan, carry add; one launch up to 8192 elements).  Used by the ball query (cell starts, list starts), the BFS output
-// assembly and the coordinate engine.  Spans are contiguous so every load/store is coalesced.
+// Device-wide exclusive prefix sum of int32 in ONE launch: a workgroup takes a contiguous span (taken in ticket order),
+// sums it, publishes the sum in a 64-bit status word (flag | value, relaxed agent-scope atomics: the payload rides in the
+// word, no fence), looks back over its predecessors' words for its prefix, and scans its span with that carry
+// (decoupled look-back; the workgroup that finishes last clears the words for the next call on the stream).  Up to
+// 8192 elements one block walks everything.  Round 3 took three launches (per-span scan, span-sum scan, carry add):
+// ~24 scans x 3 per training step, most of them inside the ball-query / clustering chains.
+// Used by the ball query (cell starts, list starts), the BFS output assembly and the coordinate engine.
+#include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "scan.h"
 
@@ -92,6 +100,98 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(int *__restrict_
     for (long i = begin + threadIdx.x; i < end; i += SCAN_THREADS) out[i] += add;
 }
 
+struct ScanState {            // one per stream, zero between calls
+    unsigned long long status[SCAN_MAX_SPANS];
+    int ticket, done;
+};
+constexpr unsigned long long SCAN_AGG = 1ull << 32, SCAN_PREFIX = 2ull << 32;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const int *in, int *out /* may alias in */, int n, int span,
+                                                                    int nspans, ScanState *__restrict__ st,
+                                                                    int *__restrict__ total_out)
+{
+    __shared__ int s_wave[SCAN_THREADS / 64];
+    __shared__ int s_bid, s_carry;
+    if (threadIdx.x == 0) s_bid = atomicAdd(&st->ticket, 1);        // spans are taken in the order the blocks START
+    __syncthreads();
+    const int bid = s_bid;
+    const long begin = (long)bid * span;
+    const long end = min((long)n, begin + span);
+    // pass A: the span's sum
+    int local = 0;
+    for (long i = begin + threadIdx.x; i < end; i += SCAN_THREADS) local += in[i];
+    local = wave_sum(local);
+    if (lane_id() == 0) s_wave[wave_id()] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; w++) total += s_wave[w];
+        int prefix = 0;
+        if (bid == 0) {
+            __hip_atomic_store(&st->status[0], SCAN_PREFIX | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&st->status[bid], SCAN_AGG | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = bid - 1;; j--) {          // every lower ticket is running or done: the wait ends
+                unsigned long long w;
+                do {
+                    w = __hip_atomic_load(&st->status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((w >> 32) == 0);
+                prefix += (int)(unsigned)w;
+                if ((w >> 32) == (SCAN_PREFIX >> 32)) break;
+            }
+            __hip_atomic_store(&st->status[bid], SCAN_PREFIX | (unsigned)(prefix + total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_carry = prefix;
+        if (bid == nspans - 1 && total_out) *total_out = prefix + total;
+    }
+    __syncthreads();
+    int carry = s_carry;
+    // pass B: the span again (L2), scanned with the carry; every element is read before the same thread overwrites it
+    for (long t0 = begin; t0 < end; t0 += SCAN_TILE) {
+        int v[SCAN_ITEMS];
+        int loc = 0;
+        const long base = t0 + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = (base + k < end) ? in[base + k] : 0;
+            loc += v[k];
+        }
+        int tot;
+        int ex = block_excl_scan(loc, &tot, s_wave) + carry;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (base + k < end) out[base + k] = ex;
+            ex += v[k];
+        }
+        carry += tot;
+    }
+    // the last block to get here leaves the state zero for the next call (all look-backs are over by then)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&st->done, 1) == nspans - 1) {
+        for (int j = 0; j < nspans; j++)
+            __hip_atomic_store(&st->status[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the look-back state of a stream (scans on one stream are ordered, scans on different streams run concurrently)
+ScanState *scan_state(hipStream_t stream)
+{
+    static std::mutex lock;
+    static std::unordered_map<hipStream_t, ScanState *> states;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = states.find(stream);
+    if (it != states.end()) return it->second;
+    ScanState *p = nullptr;
+    if (hipMalloc((void **)&p, sizeof(ScanState)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(ScanState)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    states.emplace(stream, p);
+    return p;
+}
+
 }  // namespace
 
 size_t ms3d_scan_workspace_bytes() { return ms3d_align(sizeof(int) * SCAN_MAX_SPANS); }
@@ -114,6 +214,14 @@ int ms3d_exclusive_scan_i32(const int *in, int *out, int n, int *total_out_dev, 
     int span = ms3d_divup(n, nspans);
     span = ms3d_divup(span, SCAN_TILE) * SCAN_TILE;  // whole tiles per span
     nspans = ms3d_divup(n, span);
+    static const bool chained = [] { const char *e = getenv("MS3D_SCAN_CHAINED"); return !e || atoi(e) != 0; }();
+    if (chained && nspans > 1) {
+        ScanState *st = scan_state(stream);
+        if (!st) return 10003;   // MS3D_E_INTERNAL
+        scan_chained_kernel<<<nspans, SCAN_THREADS, 0, stream>>>(in, out, n, span, nspans, st, total_out_dev);
+        MS3D_LAUNCH_CHECK();
+        return 0;
+    }
     scan_spans_kernel<<<nspans, SCAN_THREADS, 0, stream>>>(in, out, n, span, span_sums, nullptr);
     MS3D_LAUNCH_CHECK();
     scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(span_sums, nspans, total_out_dev);
@@ -123,4 +231,11 @@ int ms3d_exclusive_scan_i32(const int *in, int *out, int n, int *total_out_dev, 
         MS3D_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// exported for tests / callers of the C ABI (include/minsu3d_hip.h)
+extern "C" size_t ms3d_scan_i32_workspace_bytes(void) { return ms3d_scan_workspace_bytes(); }
+extern "C" int ms3d_scan_i32(const int *in, int *out, int n, int *total_out_dev, void *workspace, void *stream)
+{
+    return ms3d_exclusive_scan_i32(in, out, n, total_out_dev, workspace, (hipStream_t)stream);
 }

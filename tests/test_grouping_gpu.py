@@ -413,3 +413,33 @@ def test_bfs_directed_graph_leftover_clusters(be, oracle, seed):
     a, o = be.sg_bfs_cluster(mean, dev(idx), dev(sl), 0.25, 1)
     assert np.array_equal(o.cpu().numpy(), want[1])
     assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+@pytest.mark.parametrize("n", [1, 1000, 8192, 8193, 100001, 3000000, 40000000])
+def test_single_launch_scan_matches_cumsum(n):
+    """the one-launch exclusive scan (decoupled look-back, csrc/scan.hip) against torch.cumsum: out of place, in place,
+    the total, repeated on the same stream (the state must come back zeroed) and concurrently on two streams"""
+    import ctypes as C
+    from minsu3d_amd import _lib
+    lib = _lib.lib()
+    lib.ms3d_scan_i32_workspace_bytes.restype = C.c_size_t
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32).cuda()
+    want = torch.cumsum(x.long(), 0) - x.long()
+    assert int(want[-1] + x[-1]) < 2 ** 31
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    streams[1].wait_stream(streams[0])
+    outs = []
+    for rep in range(3):
+        for s_ in streams:
+            with torch.cuda.stream(s_):
+                ws = torch.empty(lib.ms3d_scan_i32_workspace_bytes() + 256, dtype=torch.uint8, device="cuda")
+                out = torch.empty_like(x) if rep < 2 else x.clone()
+                total = torch.zeros(1, dtype=torch.int32, device="cuda")
+                src = x if rep < 2 else out                      # rep 2: in place
+                _lib.check(lib.ms3d_scan_i32(_lib.ptr(src), _lib.ptr(out), n, _lib.ptr(total), _lib.ptr(ws),
+                                             C.c_void_p(s_.cuda_stream)), "ms3d_scan_i32")
+                outs.append((out, total))
+    torch.cuda.synchronize()
+    for out, total in outs:
+        assert torch.equal(out.long(), want) and int(total) == int(want[-1] + x[-1])
