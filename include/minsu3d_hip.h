@@ -341,6 +341,8 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
 int ms3d_bn_apply(const float *x, long V, int C, const float *scale, const float *shift, int relu, float *y,
                   ms3d_stream_t stream);
 int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms3d_stream_t stream);
+/* column sums of x [V, C] -> out2c[0..C) (out2c[C..2C) = column sums of squares); partial_ws: partial_rows*2*C floats */
+int ms3d_column_sum(const float *x, long V, int C, float *partial_ws, int partial_rows, float *out2c, ms3d_stream_t stream);
 int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
                       const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream);
 /* the same with `add` [V, C] (or NULL) added to the result */

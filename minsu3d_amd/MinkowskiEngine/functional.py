@@ -188,7 +188,9 @@ class DenseLinearFn(torch.autograd.Function):
         ident = be.identity_table(n, x.device)
         dx = be.conv_forward(dy, ctx.wft, ident, n, 1, cout, cin) if ctx.needs_input_grad[0] else None
         dW = be.conv_backward_weight(x, dy, ident, n, 1, cin, cout).view(cin, cout).t()
-        db = dy.sum(0) if ctx.has_bias else None
+        db = None
+        if ctx.has_bias:
+            db = be.column_sum(dy) if (hasattr(be, "column_sum") and dy.is_cuda and dy.dtype == torch.float32) else dy.sum(0)
         return dx, dW, db
 
 

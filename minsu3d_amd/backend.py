@@ -1092,6 +1092,16 @@ class _HipEngine:
                    "ms3d_bn_stats")
         return outs[0], outs[1], outs[2], outs[3]
 
+    def column_sum(self, x):
+        """x.sum(0) for a tall f32 [V, C] matrix (bias gradients of the per-point Linear layers)"""
+        x = self._dev(x)
+        V, C_ = x.shape
+        out = torch.empty((2, C_), dtype=torch.float32, device=x.device)
+        ws = self._partial_ws(C_, x.device)
+        _lib.check(self.lib.ms3d_column_sum(_lib.ptr(x), C.c_long(V), int(C_), _lib.ptr(ws), self.PARTIAL_ROWS, _lib.ptr(out),
+                                            _lib.stream_handle()), "ms3d_column_sum")
+        return out[0]
+
     def bn_finalize(self, partial, V, eps, momentum, gamma, beta, running_mean, running_var):
         """statistics from the (sum, sum of squares) partials a conv epilogue left behind -> (mean, invstd, scale, shift)"""
         if self.ext is not None:

@@ -3434,6 +3434,25 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
     return 0;
 }
 
+// out [C] = column sums of x [V, C] (the bias gradient of a per-point Linear layer over 10^5..10^6 rows: torch's sum(0)
+// of such a tall matrix takes ~60 us).  Partials (sum, sum of squares) per block of rows, reduced in fixed order;
+// partial_ws: partial_rows * 2 * C floats, out2c: 2 * C floats of which the first C are the result.
+int ms3d_column_sum(const float *x, long V, int C, float *partial_ws, int partial_rows, float *out2c, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V <= 0) {
+        MS3D_CHECK(hipMemsetAsync(out2c, 0, sizeof(float) * 2 * C, stream));
+        return 0;
+    }
+    int nblk = (int)((V + 1023) / 1024);
+    if (nblk > partial_rows) nblk = partial_rows;
+    if (nblk < 1) nblk = 1;
+    const int rows_per_block = (int)((V + nblk - 1) / nblk);
+    bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
+    MS3D_LAUNCH_CHECK();
+    return ms3d_reduce_partials(partial_ws, nblk, 2 * C, out2c, stream_);
+}
+
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
                      float *scale, float *shift, ms3d_stream_t stream)

@@ -611,3 +611,14 @@ def test_batched_backward_weight_launch_is_bit_identical(be, oracle):
         assert not queue.launches and not queue.items
         for i, (a, b2) in enumerate(zip(got, want)):
             assert torch.equal(a, b2), i
+
+
+@pytest.mark.parametrize("V,C_", [(575000, 16), (575000, 20), (5000, 3), (1, 32), (300000, 1)])
+def test_column_sum_matches_torch(be, V, C_):
+    """be.column_sum (the bias gradient of the per-point Linear layers) against a float64 column sum"""
+    torch.manual_seed(V + C_)
+    x = torch.randn(V, C_, device="cuda") * 3 + 0.5
+    got = be.column_sum(x)
+    want = x.double().sum(0)
+    assert got.shape == (C_,)
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max()))
