@@ -345,6 +345,11 @@ int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms
 int ms3d_column_sum(const float *x, long V, int C, float *partial_ws, int partial_rows, float *out2c, ms3d_stream_t stream);
 int ms3d_bn_bwd_apply(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
                       const float *invstd, const float *s1s2, float *dx, ms3d_stream_t stream);
+/* ms3d_reduce_partials + ms3d_bn_bwd_apply_add in ONE launch, bit-identical: s1s2 [2][C] = column sums of partial
+ * [nparts][2][C]; dx (or NULL: sums only) = scale * (dz - s1/V - xhat * s2/V) [+ add]; dz == dx allowed.  2C <= 1024. */
+int ms3d_bn_bwd_reduce_apply(const float *partial, int nparts, const float *dz, const float *x, long V, int C,
+                             const float *scale, const float *mean, const float *invstd, const float *add, float *dx,
+                             float *s1s2, ms3d_stream_t stream);
 /* the same with `add` [V, C] (or NULL) added to the result */
 int ms3d_bn_bwd_apply_add(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
                           const float *invstd, const float *s1s2, const float *add, float *dx, ms3d_stream_t stream);

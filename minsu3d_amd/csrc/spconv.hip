@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "../../include/minsu3d_hip.h"
 
@@ -2734,6 +2735,115 @@ __global__ __launch_bounds__(1024) void reduce_partial_kernel(const float *__res
     }
 }
 
+// reduce_partial_kernel + bn_bwd_apply_kernel in ONE launch (the BatchNorm-backward chain behind every fused backward-data
+// convolution: ~80 pairs per training step).  Workgroups take tickets in the order they start; the first ceil(2C / 16) of
+// them reduce 16 columns of the partials each -- the arithmetic of reduce_partial_kernel, same lanes, same order -- and
+// PUBLISH the sums as 64-bit words (flag | float bits) with relaxed agent-scope atomic stores (the payload rides in the
+// word: no fence, no L2 write-back; the XCDs' L2s are not coherent with each other); every workgroup then collects the
+// 2C words (spinning on a word only until its reducer, which holds a lower ticket and is therefore running or done, has
+// stored it) and applies dx = scale * (dz - s1/V - xhat * s2/V) [+ add] to its share of the rows with the expression of
+// bn_bwd_apply_kernel.  The workgroup that finishes last clears the words for the next launch on the stream.
+struct BnBwdState {
+    unsigned long long word[1024];   // 2C <= 1024
+    int ticket, done;
+};
+
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_apply_kernel(const float *__restrict__ partial, int nparts, const float *dz,
+                                                                  const float *__restrict__ x, long n, int C, long V,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ invstd,
+                                                                  const float *__restrict__ add, float *dx,
+                                                                  float *__restrict__ s1s2_out, BnBwdState *__restrict__ st)
+{
+    __shared__ double s_sum[16][17];
+    __shared__ float s_s[1024];
+    __shared__ int s_bid;
+    const int n2 = 2 * C, nred = (n2 + 15) / 16;
+    if (threadIdx.x == 0) s_bid = atomicAdd(&st->ticket, 1);
+    __syncthreads();
+    const int bid = s_bid;
+    if (bid < nred) {
+        const int col = bid * 16 + (threadIdx.x & 15), lane_p = threadIdx.x >> 4;
+        double s = 0.0;
+        if (col < n2)
+            for (int p = lane_p; p < nparts; p += 64) s += (double)partial[(size_t)p * n2 + col];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if ((threadIdx.x & 63) < 16) s_sum[threadIdx.x >> 6][threadIdx.x & 15] = s;
+        __syncthreads();
+        if (threadIdx.x < 16 && col < n2) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) t += s_sum[i][threadIdx.x];
+            const float f = (float)t;
+            s1s2_out[col] = f;
+            __hip_atomic_store(&st->word[col], (1ull << 32) | (unsigned long long)__float_as_uint(f), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int t = threadIdx.x; t < n2; t += 1024) {
+        unsigned long long w;
+        do {
+            w = __hip_atomic_load(&st->word[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w >> 32) == 0);
+        s_s[t] = __uint_as_float((unsigned)w);
+    }
+    __syncthreads();
+    if (dx) {
+        const float invV = 1.f / (float)V;
+        const long stride = (long)gridDim.x * 1024;
+        if ((C & 3) == 0) {
+            const long n4 = n >> 2;
+            const int C4 = C >> 2;
+            for (long v = (long)bid * 1024 + threadIdx.x; v < n4; v += stride) {
+                const int c = (int)(v % C4) * 4;
+                const float4 xv = reinterpret_cast<const float4 *>(x)[v], g = reinterpret_cast<const float4 *>(dz)[v];
+                const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+                const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+                const float4 a1 = *reinterpret_cast<const float4 *>(s_s + c), a2 = *reinterpret_cast<const float4 *>(s_s + C + c);
+                float4 o;
+                o.x = sc.x * (g.x - a1.x * invV - ((xv.x - mu.x) * is.x) * a2.x * invV);
+                o.y = sc.y * (g.y - a1.y * invV - ((xv.y - mu.y) * is.y) * a2.y * invV);
+                o.z = sc.z * (g.z - a1.z * invV - ((xv.z - mu.z) * is.z) * a2.z * invV);
+                o.w = sc.w * (g.w - a1.w * invV - ((xv.w - mu.w) * is.w) * a2.w * invV);
+                if (add) {
+                    const float4 r = reinterpret_cast<const float4 *>(add)[v];
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                reinterpret_cast<float4 *>(dx)[v] = o;
+            }
+        } else {
+            for (long e = (long)bid * 1024 + threadIdx.x; e < n; e += stride) {
+                const int c = (int)(e % C);
+                const float xh = (x[e] - mean[c]) * invstd[c];
+                const float o = scale[c] * (dz[e] - s_s[c] * invV - xh * s_s[C + c] * invV);
+                dx[e] = add ? o + add[e] : o;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&st->done, 1) == (int)gridDim.x - 1) {
+        for (int t = 0; t < n2; t++) __hip_atomic_store(&st->word[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+BnBwdState *bn_bwd_state(hipStream_t stream)
+{
+    static std::mutex lock;
+    static std::unordered_map<hipStream_t, BnBwdState *> states;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = states.find(stream);
+    if (it != states.end()) return it->second;
+    BnBwdState *p = nullptr;
+    if (hipMalloc((void **)&p, sizeof(BnBwdState)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(BnBwdState)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    states.emplace(stream, p);
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -3484,6 +3594,33 @@ int ms3d_reduce_partials(const float *partial, int nparts, int n, float *out, ms
     return 0;
 }
 
+// s1s2 [2][C] = column sums of partial [nparts][2][C], and (dx != NULL) dx = scale * (dz - s1/V - xhat * s2/V) [+ add], in
+// ONE launch (bn_bwd_reduce_apply_kernel); bit-identical to ms3d_reduce_partials + ms3d_bn_bwd_apply_add
+int ms3d_bn_bwd_reduce_apply(const float *partial, int nparts, const float *dz, const float *x, long V, int C,
+                             const float *scale, const float *mean, const float *invstd, const float *add, float *dx,
+                             float *s1s2, ms3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    static const bool fused = [] { const char *e = getenv("MS3D_BN_BWD_FUSED"); return !e || atoi(e) != 0; }();
+    if (!fused || 2 * C > 1024 || V <= 0) {
+        int rc = ms3d_reduce_partials(partial, nparts, 2 * C, s1s2, stream_);
+        if (rc || !dx) return rc;
+        return ms3d_bn_bwd_apply_add(dz, x, V, C, scale, mean, invstd, s1s2, add, dx, stream_);
+    }
+    BnBwdState *st = bn_bwd_state(stream);
+    if (!st) return MS3D_E_INTERNAL;
+    const long n = V * C;
+    const long work = dx ? ((C & 3) == 0 ? n / 4 : n) : 0;
+    const int nred = ms3d_divup(2 * C, 16);
+    long blocks = (work + 4095) / 4096;          // ~4 items per thread
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < nred) blocks = nred;
+    bn_bwd_reduce_apply_kernel<<<(int)blocks, 1024, 0, stream>>>(partial, nparts, dz, x, n, C, V, scale, mean, invstd, add, dx,
+                                                               s1s2, st);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int ms3d_bn_bwd_apply_add(const float *dz, const float *x, long V, int C, const float *scale, const float *mean,
                           const float *invstd, const float *s1s2, const float *add, float *dx, ms3d_stream_t stream)
 {
@@ -3665,12 +3802,16 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             if (rc) return rc;
             if (ev_stop) MS3D_CHECK(hipEventRecord((hipEvent_t)ev_stop, main));
             ev_stop = nullptr;
-            rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
-            if (rc) return rc;
-            if (need_dx) {
-                if (training) {
-                    rc = ms3d_bn_bwd_apply_add(dx, x, Vin, Cin, scale, mean, invstd, dgb, dx_add, dx, stream);
-                } else {
+            if (need_dx && training) {
+                // slab of sums + the elementwise BatchNorm-backward pass in one launch
+                rc = ms3d_bn_bwd_reduce_apply(partial, nparts, dx, x, Vin, Cin, scale, mean, invstd, dx_add, dx, dgb, stream);
+                if (rc) return rc;
+            } else {
+                rc = ms3d_reduce_partials(partial, nparts, 2 * Cin, dgb, stream);
+                if (rc) return rc;
+            }
+            if (need_dx && !training) {
+                {
                     if (dx_add) return MS3D_E_UNSUPPORTED;   // eval-mode statistics: the caller adds the skip gradient itself
                     rc = ms3d_bn_apply(dx, Vin, Cin, scale, nullptr, 0, dx, stream);  // dx = dz * scale
                 }

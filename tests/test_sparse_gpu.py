@@ -622,3 +622,42 @@ def test_column_sum_matches_torch(be, V, C_):
     want = x.double().sum(0)
     assert got.shape == (C_,)
     assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("V,C_,nparts,with_add", [(112360, 16, 256, True), (52696, 32, 512, False), (2591, 80, 810, True),
+                                                   (112, 112, 49, False), (200697, 48, 1024, True), (7, 20, 3, True)])
+def test_fused_bn_backward_chain_is_bit_identical(be, V, C_, nparts, with_add):
+    """ms3d_bn_bwd_reduce_apply (partial sums + the elementwise BatchNorm-backward pass in one launch, the sums handed
+    between workgroups through atomic words) against ms3d_reduce_partials + ms3d_bn_bwd_apply_add: the same bits, in place,
+    repeatedly on one stream (the hand-over state must come back clean) and on a second stream"""
+    import ctypes as C
+    lib = be.lib
+    torch.manual_seed(V + C_)
+    x = torch.randn(V, C_, device="cuda") * 2 + 0.3
+    dz = torch.randn(V, C_, device="cuda")
+    partial = torch.randn(nparts, 2, C_, device="cuda")
+    scale, mean, invstd = (torch.rand(C_, device="cuda") + 0.5 for _ in range(3))
+    add = torch.randn(V, C_, device="cuda") if with_add else None
+    want_s = torch.empty(2, C_, device="cuda"); want_dx = torch.empty_like(dz)
+    _lib = __import__("minsu3d_amd._lib", fromlist=["ptr"])
+    p = _lib.ptr
+    st = _lib.stream_handle()
+    _lib.check(lib.ms3d_reduce_partials(p(partial), nparts, 2 * C_, p(want_s), st), "reduce")
+    _lib.check(lib.ms3d_bn_bwd_apply_add(p(dz), p(x), C.c_long(V), C_, p(scale), p(mean), p(invstd), p(want_s), p(add),
+                                         p(want_dx), st), "apply")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for rep in range(4):
+        stream = side if rep == 3 else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            got_s = torch.empty(2, C_, device="cuda")
+            buf = dz.clone()                                       # in place: dz == dx
+            _lib.check(lib.ms3d_bn_bwd_reduce_apply(p(partial), nparts, p(buf), p(x), C.c_long(V), C_, p(scale), p(mean),
+                                                    p(invstd), p(add), p(buf), p(got_s), C.c_void_p(stream.cuda_stream)),
+                       "fused")
+        stream.synchronize()
+        assert torch.equal(got_s, want_s) and torch.equal(buf, want_dx), rep
+    sums_only = torch.empty(2, C_, device="cuda")
+    _lib.check(lib.ms3d_bn_bwd_reduce_apply(p(partial), nparts, None, None, C.c_long(V), C_, None, None, None, None, None,
+                                            p(sums_only), st), "fused sums")
+    assert torch.equal(sums_only, want_s)
