@@ -3601,7 +3601,11 @@ int ms3d_bn_bwd_reduce_apply(const float *partial, int nparts, const float *dz, 
                              float *s1s2, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    static const bool fused = [] { const char *e = getenv("MS3D_BN_BWD_FUSED"); return !e || atoi(e) != 0; }();
+    // OFF by default: measured SLOWER than the two launches it replaces (profiles/r04_experiments.txt section 6: 15.1 us
+    // per launch against 7.6 + 4.9 us, median PointGroup step 20.99 against 20.48 ms) -- the hand-over of the sums through
+    // atomic words costs every workgroup a fabric round trip at its start, more than the saved launch.  Kept as a tested,
+    // bit-identical option (MS3D_BN_BWD_FUSED=1: 1110 -> 1033 launches per PointGroup step).
+    static const bool fused = [] { const char *e = getenv("MS3D_BN_BWD_FUSED"); return e && atoi(e) != 0; }();
     if (!fused || 2 * C > 1024 || V <= 0) {
         int rc = ms3d_reduce_partials(partial, nparts, 2 * C, s1s2, stream_);
         if (rc || !dx) return rc;
