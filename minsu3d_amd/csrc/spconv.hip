@@ -3318,10 +3318,21 @@ int ms3d_spconv_wgrad_is_table_walk(int Vout, int K, int Cin, int Cout, int offs
     const bool use_list = offset_list && ms3d_divup(Cout, 16) <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     return (Vout > 0 && !use_list && !wgrad_bf3_ok(Vout, K, Cin, Cout, use_list) && ms3d_divup(Cout, 16) <= 14) ? 1 : 0;
 }
+// K = 1 with a small weight (the per-point Linear layers of the heads: 575k rows x 16 -> 16 / 20 / 3): the table walk's
+// grid is (row chunks) x 1 x Cin / 16, so 256 chunks are ONE workgroup per CU walking 2200 rows each in dependent trips of 32
+// (107 us per launch); the slabs are a few hundred floats, so the rows are cut 8x finer instead (measured below)
+static int wgrad_k1_chunks(int Vout, int K, int Cin, int Cout)
+{
+    static const int k1_max = [] { const char *e = getenv("MS3D_WGRAD_K1_CHUNKS"); return e ? atoi(e) : 2048; }();
+    if (K != 1 || (long)Cin * Cout > 4096 || k1_max <= 0) return 0;
+    int c = ms3d_divup(Vout, 128);
+    return c > k1_max ? k1_max : c;
+}
 // slabs + (bf16x3 kernel) the dout operand image and the activated input pieces
 size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout)
 {
-    size_t n = (size_t)ms3d_spconv_wgrad_row_chunks(Vout) * K * Cin * Cout + 64;
+    const int k1 = wgrad_k1_chunks(Vout, K, Cin, Cout), rc = ms3d_spconv_wgrad_row_chunks(Vout);
+    size_t n = (size_t)(k1 > rc ? k1 : rc) * K * Cin * Cout + 64;
     if (wgrad_bf3_ok(Vout, K, Cin, Cout, false)) {
         n += (size_t)ms3d_divup(Vout, 32) * ms3d_divup(Cout, 16) * 3 * 64 * 4 + 8;        // dout image, 16 B units
         n += (size_t)Vout * Cin * 3 / 2 + 8;                                                 // 6 B per input element
@@ -3410,6 +3421,8 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
                 if (c < 4) c = 4;
                 if (c < chunks) chunks = c;
             }
+            const int k1 = wgrad_k1_chunks(Vout, K, Cin, Cout);
+            if (k1 > chunks) chunks = k1;
         }
         p.rows_per_block = ms3d_divup(ms3d_divup(Vout, chunks), 16) * 16;
         nblk = ms3d_divup(Vout, p.rows_per_block);
