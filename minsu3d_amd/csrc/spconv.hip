@@ -3320,10 +3320,12 @@ int ms3d_spconv_wgrad_is_table_walk(int Vout, int K, int Cin, int Cout, int offs
 }
 // K = 1 with a small weight (the per-point Linear layers of the heads: 575k rows x 16 -> 16 / 20 / 3): the table walk's
 // grid is (row chunks) x 1 x Cin / 16, so 256 chunks are ONE workgroup per CU walking 2200 rows each in dependent trips of 32
-// (107 us per launch); the slabs are a few hundred floats, so the rows are cut 8x finer instead (measured below)
+// (107 us per launch); the slabs are a few hundred floats, so the rows are cut 4x finer instead (measured below)
 static int wgrad_k1_chunks(int Vout, int K, int Cin, int Cout)
 {
-    static const int k1_max = [] { const char *e = getenv("MS3D_WGRAD_K1_CHUNKS"); return e ? atoi(e) : 2048; }();
+    // us per call incl. the slab reduction, 575k rows x 16 -> 16 / 20 / 3, by chunk limit (tools/scripts/k1_sweep.sh):
+    // 256: 103 / 96 / 100;  1024: 70 / 73 / 68;  2048: 76 / 81 / 73;  4096: 109 / 120 / 102
+    static const int k1_max = [] { const char *e = getenv("MS3D_WGRAD_K1_CHUNKS"); return e ? atoi(e) : 1024; }();
     if (K != 1 || (long)Cin * Cout > 4096 || k1_max <= 0) return 0;
     int c = ms3d_divup(Vout, 128);
     return c > k1_max ? k1_max : c;
