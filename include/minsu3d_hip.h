@@ -267,7 +267,8 @@ int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps,
  * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
 int ms3d_spconv_wgrad_row_chunks(int Vout);
 /* floats of partial_ws a backward-weight call may use (slabs; wide K = 27 layers add the three-piece bf16 images of both
- * operands).  K = 27 is the submanifold case: `in` and `dout` have the same Vout rows. */
+ * operands).  K = 27 is the SUBMANIFOLD case: `in` and `dout` have the same Vout rows -- a 27-offset table whose input row
+ * set differs from its output row set is outside this entry point's contract (the bf16x3 path splits Vout rows of `in`). */
 size_t ms3d_spconv_wgrad_ws_floats(int Vout, int K, int Cin, int Cout);
 /* 1 when a backward-weight call of this shape runs on three-piece bf16 operands (offset_list: an offset list is passed) */
 int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_list);

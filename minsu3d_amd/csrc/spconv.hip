@@ -1081,6 +1081,12 @@ int launch_fwd_small_bf3(const ConvArgs &p, dim3 grid, int threads, size_t lds, 
 template <int NBT>
 int launch_fwd_small(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool aligned, hipStream_t stream)
 {
+    // The geometry may have been laid out for the bf16x3 three-tile kernel (4 waves x RT x nbt KB of LDS, 72-96+ KB at
+    // >= 96 output channels) while this call has no bf16x3 image (the exact-f32 entry point, a BatchNorm without ReLU,
+    // aux kind 1): this kernel parks (waves - 1) x nbt accumulator tiles + the statistics only -- ask for that, not for
+    // the other kernel's footprint (which would exceed the 64 KB a kernel gets without raising its ceiling)
+    const size_t need = ((size_t)(threads / 64 - 1) * NBT * 256 + ((p.bn_x || p.out_stats) ? 2 * (size_t)p.Cout : 0)) * sizeof(float) + 16;
+    if (lds > need) lds = need;
     if (aligned)
         spconv_fwd_small_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
     else
@@ -3307,8 +3313,12 @@ static bool wgrad_bf3_ok(int Vout, int K, int Cin, int Cout, bool use_list)
     if ((double)Vout * Cin * Cout < 30e6) return false;
     static const bool wg = [] { const char *e = getenv("MS3D_BF16X3_WGRAD"); return !e || atoi(e) != 0; }();
     const int nb = ms3d_divup(Cout, 16);
-    // K == 27: submanifold tables, input rows = output rows (the exported entry point is not told the input row count)
-    return bf3_enabled() && wg && !use_list && K == 27 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin % 16 == 0 && Cout % 16 == 0;
+    // K == 27: submanifold tables, input rows = output rows (the exported entry point is not told the input row count; a
+    // K = 27 table whose input has OTHER rows than its output -- not a submanifold map, nothing in this package builds
+    // one -- must not be handed to ms3d_spconv_backward_weight at these sizes: documented in the header).
+    // Cin <= 256: the packed gather entry keeps the source word in 8 bits (as bf3_dims_ok)
+    return bf3_enabled() && wg && !use_list && K == 27 && nb >= 3 && nb <= 8 && Cin >= 48 && Cin <= 256 && Cin % 16 == 0 &&
+           Cout % 16 == 0;
 }
 int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_list) { return wgrad_bf3_ok(Vout, K, Cin, Cout, offset_list != 0) ? 1 : 0; }
 // 1 when a backward-weight call of this shape takes the f32 table walk -- the kernel ms3d_spconv_layer_backward can leave
