@@ -551,3 +551,57 @@ def test_fused_point_losses_match_the_torch_formulation(n, C_, valid):
     assert (gof - got_).abs().max().item() <= 2e-5 * max(got_.abs().max().item(), 1e-12) + 1e-12
     if valid == 0.0:
         assert lf[1] == 0.0 and lf[2] == 0.0 and float(gof.abs().max()) == 0.0
+
+
+def test_fused_residual_blocks_give_the_same_step(monkeypatch):
+    """ResidualBlock as ONE autograd node (ME.functional.ResBlockFn: the same four library calls forward, the same two
+    backward, only the interpreter work between them is gone) against the module chain: same proposals, losses and
+    gradients of a training step up to the float-atomic noise of the training-mode statistics, same running statistics
+    and batch counters; inner-module hooks switch a block back to the module chain."""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    from minsu3d_amd.model.module import common
+    backend.set_backend(HipBackend())
+    u = tuple(t.cuda() for t in (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3])))
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((31, 32)).items()}
+    base = build_model(seed=9)
+    res = []
+    calls = []
+    real_apply = common.ME_F.ResBlockFn.apply
+    monkeypatch.setattr(common.ME_F.ResBlockFn, "apply", staticmethod(lambda *a: (calls.append(1), real_apply(*a))[1]))
+    for fused in (True, False):
+        monkeypatch.setattr(common, "_FUSE_BLOCKS", fused)
+        m = copy.deepcopy(base).cuda()
+        m.voxelization_rand = u
+        m.train()
+        n0 = len(calls)
+        out = m(b)
+        losses = m._loss(b, out)
+        sum(losses.values()).backward()
+        assert (len(calls) > n0) == fused
+        sd = m.state_dict()
+        res.append((out, {k: float(v.detach()) for k, v in losses.items()},
+                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in sd.items() if "running" in k or "num_batches" in k}))
+    n_blocks = len(calls)
+    assert n_blocks >= 10                                            # most blocks of the two U-Nets took the fused node
+    (o1, l1, g1, s1), (o2, l2, g2, s2) = res
+    assert torch.equal(o1["proposal_scores"][1], o2["proposal_scores"][1])
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-4 * max(abs(l2[k]), 1e-3), (k, l1[k], l2[k])
+    assert g1.keys() == g2.keys()
+    for n in g1:
+        scale = g2[n].abs().max().item()
+        assert (g1[n] - g2[n]).abs().max().item() <= 2e-3 * scale + 1e-6, n      # (analytically zero gradients are 1e-8 noise)
+    for k in s1:
+        assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-4, atol=1e-6), k
+    # a forward hook on an inner module: that block takes the module chain (the hook fires)
+    monkeypatch.setattr(common, "_FUSE_BLOCKS", True)
+    m = copy.deepcopy(base).cuda(); m.voxelization_rand = u; m.train()
+    blk = m.backbone.unet[1].blocks.block0
+    seen = []
+    h = blk.conv_branch[1].register_forward_hook(lambda mod, i, o: seen.append(1))
+    n0 = len(calls)
+    m(b)
+    h.remove()
+    assert seen and len(calls) - n0 == n_blocks - 1
