@@ -180,6 +180,49 @@ class ResBlockFn(torch.autograd.Function):
         return dx, dW1.view_as(W1), dgb0[1], dgb0[0], dW2.view_as(W2), dgb1[1], dgb1[0], None, None, None, None, None
 
 
+class BnReluConvFn(torch.autograd.Function):
+    """[BatchNorm, ReLU, convolution] in training mode -- the strided / transposed convolutions between the U-Net levels --
+    as one autograd node: bn_finalize + the fused convolution forward, the fused backward call (see ResBlockFn: the same
+    library calls as the module chain, without its interpreter work)."""
+
+    @staticmethod
+    def forward(ctx, x, W, g, b, spec, stats_in, bn, want_stats):
+        be = get_backend()
+        tok = getattr(be, "weight_token", None)
+        if isinstance(stats_in, tuple):
+            m0, i0, s0, h0 = be.bn_finalize_parts(stats_in, spec.vin, bn.eps, bn.momentum, g.detach(), b.detach(),
+                                                  bn.running_mean, bn.running_var)
+        else:
+            m0, i0, s0, h0 = be.bn_finalize(stats_in, spec.vin, bn.eps, bn.momentum, g.detach(), b.detach(), bn.running_mean,
+                                            bn.running_var)
+        r = getattr(W, "_ms3d_wf", None)
+        r = r[0] if (r is not None and r[1] == tok) else None
+        y, st, wf = be.conv_layer_forward(x, W.view(spec.K, spec.cin, spec.cout), spec.nbr_fwd, spec.vout, spec.K, spec.cin,
+                                          spec.cout, spec.mirror, (s0, h0), True, None, None, want_stats,
+                                          **({"wf_ready": r} if r is not None else {}))
+        ctx.spec, ctx.wf = spec, wf
+        ctx.bn = dict(scale=s0.contiguous(), shift=h0.contiguous(), mean=m0.contiguous(), invstd=i0.contiguous(), relu=True,
+                      training=True)
+        d = getattr(W, "_ms3d_defer", None)
+        ctx.defer = d[0] if (d is not None and d[1] == tok) else None
+        ctx.save_for_backward(x, W)
+        if st is None:
+            st = x.new_zeros(0)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        be = get_backend()
+        spec = ctx.spec
+        x, W = ctx.saved_tensors
+        e = {"defer": ctx.defer} if ctx.defer is not None else {}
+        dx, dgb, dW = be.conv_layer_backward(x, dy.contiguous(), ctx.wf, spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout, spec.K,
+                                             spec.cin, spec.cout, ctx.bn, ctx.needs_input_grad[0], **e)
+        return dx, dW.view_as(W), dgb[1], dgb[0], None, None, None, None
+
+
 class BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, bn):

@@ -106,6 +106,44 @@ class ResidualBlock(nn.Module):
         return layers[-1](h, residual=skip)
 
 
+def _bn_relu_conv_fused(seq, x):
+    """Sequential(BatchNorm, ReLU, strided / transposed convolution) as one autograd node (ME.functional.BnReluConvFn) in
+    training mode when the input still carries its producer's statistics; otherwise (and when somebody hooks an inner
+    module) the module chain"""
+    if (_FUSE_BLOCKS is False or not seq.training or not torch.is_grad_enabled() or x._pending is not None or not x._F.is_cuda
+            or x._stats is None or (torch.is_tensor(x._stats) and x._stats.numel() == 0)):
+        return seq(x)
+    plan = seq.__dict__.get("_fuse_plan")
+    if plan is None:
+        ok = (len(seq) == 3 and isinstance(seq[0], ME.MinkowskiBatchNorm) and isinstance(seq[1], ME.MinkowskiReLU)
+              and isinstance(seq[2], (ME.MinkowskiConvolution, ME.MinkowskiConvolutionTranspose))
+              and seq[2].kernel_size == 2 and seq[2].stride == 2
+              and seq[0].bn.affine and seq[0].bn.track_running_stats and seq[0].bn.momentum is not None)
+        plan = seq.__dict__["_fuse_plan"] = tuple(seq) if ok else ()
+    if not plan or getattr(get_backend(), "name", "") != "hip" or seq._forward_hooks or seq._forward_pre_hooks:
+        return seq(x)
+    for m in plan:
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
+            return seq(x)
+    bn, _, conv = plan
+    st = x._stats
+    if isinstance(st, tuple) and sum(p.size(2) for p in st) != x._F.size(1):
+        return seq(x)
+    cm, ts = x.coordinate_manager, x.tensor_stride
+    if isinstance(conv, ME.MinkowskiConvolutionTranspose):
+        fine = ts // 2
+        down, up = cm.k2(fine)
+        spec = ME_F.ConvSpec(up, down, cm.size(ts), cm.size(fine), 8, conv.in_channels, conv.out_channels, False)
+        out_ts = fine
+    else:
+        down, up = cm.k2(ts)
+        spec = ME_F.ConvSpec(down, up, cm.size(ts), cm.size(2 * ts), 8, conv.in_channels, conv.out_channels, False)
+        out_ts = 2 * ts
+    y, stats = ME_F.BnReluConvFn.apply(x._F, conv._kernel(), bn.bn.weight, bn.bn.bias, spec, st, bn.bn, True)
+    bn._pending_batches += 1
+    return x._like(y, tensor_stride=out_ts, stats=stats)
+
+
 class UBlock(nn.Module):
     """recursive encoder/decoder level; n_planes = channel widths from this level down"""
 
@@ -128,5 +166,5 @@ class UBlock(nn.Module):
         skip = self.blocks(x)
         if len(self.nPlanes) == 1:
             return skip
-        up = self.deconv(self.u(self.conv(skip)))
+        up = _bn_relu_conv_fused(self.deconv, self.u(_bn_relu_conv_fused(self.conv, skip)))
         return self.blocks_tail(ME.cat(skip, up))
