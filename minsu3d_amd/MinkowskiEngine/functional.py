@@ -180,6 +180,70 @@ class ResBlockFn(torch.autograd.Function):
         return dx, dW1.view_as(W1), dgb0[1], dgb0[0], dW2.view_as(W2), dgb1[1], dgb1[0], None, None, None, None, None
 
 
+class ResBlockDownFn(torch.autograd.Function):
+    """The residual block with a 1x1 projection on its skip path (the first block behind a skip concatenation):
+    out = x W_d + conv2(relu(bn1(conv1(relu(bn0(x)))))) as one autograd node -- the projection (K = 1 convolution), the
+    two bn_finalize (bn0 over the concatenation's parts) and the two fused convolutions forward; backward: the two fused
+    backward calls of the branch, then the projection's, whose residual epilogue adds the branch's dx (the module chain
+    leaves that sum to an elementwise autograd kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, Wd, W1, g0, b0, W2, g1, b1, spec, ident, stats_in, bn0, bn1):
+        be = get_backend()
+        V, cin, cout = spec.vout, spec.cin, spec.cout
+        tok = getattr(be, "weight_token", None)
+
+        def ready(W):
+            r = getattr(W, "_ms3d_wf", None)
+            return {"wf_ready": r[0]} if (r is not None and r[1] == tok) else {}
+
+        skip, _, wfd = be.conv_layer_forward(x, Wd.view(1, cin, cout), ident, V, 1, cin, cout, False, None, False, None, None,
+                                             False, **ready(Wd))
+        if isinstance(stats_in, tuple):
+            m0, i0, s0, h0 = be.bn_finalize_parts(stats_in, V, bn0.eps, bn0.momentum, g0.detach(), b0.detach(),
+                                                  bn0.running_mean, bn0.running_var)
+        else:
+            m0, i0, s0, h0 = be.bn_finalize(stats_in, V, bn0.eps, bn0.momentum, g0.detach(), b0.detach(), bn0.running_mean,
+                                            bn0.running_var)
+        y1, st1, wf1 = be.conv_layer_forward(x, W1, spec.nbr_fwd, V, 27, cin, cout, True, (s0, h0), True, None, None, True,
+                                             **ready(W1))
+        m1, i1, s1, h1 = be.bn_finalize(st1, V, bn1.eps, bn1.momentum, g1.detach(), b1.detach(), bn1.running_mean,
+                                        bn1.running_var)
+        y2, st2, wf2 = be.conv_layer_forward(y1, W2, spec.nbr_fwd, V, 27, cout, cout, True, (s1, h1), True, skip, None, True,
+                                             **ready(W2))
+        ctx.spec, ctx.wf, ctx.ident = spec, (wfd, wf1, wf2), ident
+        ctx.bn = (dict(scale=s0.contiguous(), shift=h0.contiguous(), mean=m0.contiguous(), invstd=i0.contiguous(), relu=True,
+                       training=True),
+                  dict(scale=s1, shift=h1, mean=m1, invstd=i1, relu=True, training=True))
+
+        def queue(W):
+            d = getattr(W, "_ms3d_defer", None)
+            return d[0] if (d is not None and d[1] == tok) else None
+
+        ctx.defer = (queue(Wd), queue(W1), queue(W2))
+        ctx.save_for_backward(x, y1, Wd, W1, W2)
+        ctx.mark_non_differentiable(st2)
+        ctx.set_materialize_grads(False)
+        return y2, st2
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        be = get_backend()
+        spec = ctx.spec
+        x, y1, Wd, W1, W2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        V, cin, cout = spec.vout, spec.cin, spec.cout
+        ex = lambda q: ({"defer": q} if q is not None else {})
+        dx1, dgb1, dW2 = be.conv_layer_backward(y1, dy, ctx.wf[2], spec.nbr_fwd, spec.nbr_bwd, V, V, 27, cout, cout, ctx.bn[1],
+                                                True, **ex(ctx.defer[2]))
+        need = ctx.needs_input_grad[0]
+        dxb, dgb0, dW1 = be.conv_layer_backward(x, dx1, ctx.wf[1], spec.nbr_fwd, spec.nbr_bwd, V, V, 27, cin, cout, ctx.bn[0],
+                                                need, **ex(ctx.defer[1]))
+        dx, _, dWd = be.conv_layer_backward(x, dy, ctx.wf[0], ctx.ident, ctx.ident, V, V, 1, cin, cout, None, need,
+                                            **({"dx_add": dxb} if need else {}), **ex(ctx.defer[0]))
+        return dx, dWd.view_as(Wd), dW1.view_as(W1), dgb0[1], dgb0[0], dW2.view_as(W2), dgb1[1], dgb1[0], None, None, None, None, None
+
+
 class BnReluConvFn(torch.autograd.Function):
     """[BatchNorm, ReLU, convolution] in training mode -- the strided / transposed convolutions between the U-Net levels --
     as one autograd node: bn_finalize + the fused convolution forward, the fused backward call (see ResBlockFn: the same

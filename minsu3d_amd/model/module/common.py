@@ -38,13 +38,18 @@ class ResidualBlock(nn.Module):
         self.conv_branch = nn.Sequential(*first, *second)
 
     def _fused(self, x):
-        """the whole block as one autograd node (ME_F.ResBlockFn) when nothing but the plain training-mode chain is
-        asked for; None = take the module chain"""
-        if (self.downsample is not None or not self.training or not torch.is_grad_enabled() or x._pending is not None
-                or not torch.is_tensor(x._stats) or x._stats.numel() == 0 or not x._F.is_cuda or _FUSE_BLOCKS is False):
+        """the whole block as one autograd node (ME.functional.ResBlockFn, or ResBlockDownFn when the skip path has its
+        1x1 projection) when nothing but the plain training-mode chain is asked for; None = take the module chain"""
+        if (not self.training or not torch.is_grad_enabled() or x._pending is not None or _FUSE_BLOCKS is False
+                or not x._F.is_cuda):
             return None
-        be = get_backend()
-        if getattr(be, "name", "") != "hip":
+        st = x._stats
+        if isinstance(st, tuple):
+            if self.downsample is None or sum(p.size(2) for p in st) != x._F.size(1):
+                return None
+        elif not torch.is_tensor(st) or st.numel() == 0:
+            return None
+        if getattr(get_backend(), "name", "") != "hip":
             return None
         cb = self.conv_branch
         plan = self.__dict__.get("_fuse_plan")
@@ -54,21 +59,32 @@ class ResidualBlock(nn.Module):
                   and isinstance(cb[4], ME.MinkowskiReLU) and isinstance(cb[5], ME.MinkowskiConvolution)
                   and all(c.kernel_size == 3 and c.stride == 1 for c in (cb[2], cb[5]))
                   and all(b.bn.affine and b.bn.track_running_stats and b.bn.momentum is not None for b in (cb[0], cb[3]))
-                  and cb[2].out_channels == cb[5].in_channels == cb[5].out_channels)
-            plan = self.__dict__["_fuse_plan"] = tuple(cb) if ok else ()
+                  and cb[2].out_channels == cb[5].in_channels == cb[5].out_channels
+                  and (self.downsample is None or (len(self.downsample) == 1
+                                                   and isinstance(self.downsample[0], ME.MinkowskiConvolution)
+                                                   and self.downsample[0].kernel_size == 1 and self.downsample[0].stride == 1
+                                                   and self.downsample[0].kernel.dim() == 2)))
+            plan = self.__dict__["_fuse_plan"] = (tuple(cb) + (tuple(self.downsample) if self.downsample is not None else ())) if ok else ()
         if not plan:
             return None
         for m in plan:            # somebody is watching an inner module: its hooks must fire
             if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
                 return None
-        bn0, _, conv1, bn1, _, conv2 = plan
+        bn0, _, conv1, bn1, _, conv2 = plan[:6]
         if not conv1.kernel.is_cuda:
             return None
         cm, ts = x.coordinate_manager, x.tensor_stride
         nbr, V = cm.k3(ts), cm.size(ts)
         spec = ME_F.ConvSpec(nbr, nbr, V, V, 27, conv1.in_channels, conv1.out_channels, True)
-        y, stats = ME_F.ResBlockFn.apply(x._F, conv1._kernel(), bn0.bn.weight, bn0.bn.bias, conv2._kernel(),
-                                                  bn1.bn.weight, bn1.bn.bias, spec, x._stats, bn0.bn, bn1.bn, True)
+        if self.downsample is None:
+            y, stats = ME_F.ResBlockFn.apply(x._F, conv1._kernel(), bn0.bn.weight, bn0.bn.bias, conv2._kernel(),
+                                             bn1.bn.weight, bn1.bn.bias, spec, st, bn0.bn, bn1.bn, True)
+        else:
+            if self.downsample._forward_hooks or self.downsample._forward_pre_hooks:
+                return None
+            y, stats = ME_F.ResBlockDownFn.apply(x._F, plan[6]._kernel(), conv1._kernel(), bn0.bn.weight, bn0.bn.bias,
+                                                 conv2._kernel(), bn1.bn.weight, bn1.bn.bias, spec, cm.identity(ts), st, bn0.bn,
+                                                 bn1.bn)
         bn0._pending_batches += 1
         bn1._pending_batches += 1
         return x._like(y, stats=stats)
