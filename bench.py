@@ -90,7 +90,7 @@ def train_step(model, ddp, opt, batch, next_batch=None):
     if next_batch is not None:
         def prefetch():
             ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
-                                    channels=model.backbone.level_channels)
+                                    channels=model.backbone.level_channels, point_map=next_batch["voxel_point_map"])
         if PREFETCH_AT == "grouping":
             model.schedule_after_backbone(prefetch)
     out = ddp(batch)

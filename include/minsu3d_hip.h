@@ -134,6 +134,11 @@ int ms3d_gather_rows(const float *x, const long long *idx /* int64 */, long n, i
  * feats[c_idxs], features[p2v_map] (reference backbone.py:40, general_model.py:156, pointgroup.py:88) */
 int ms3d_scatter_add_rows(const float *src, const long long *idx /* int64 */, long n, int C, float *dst,
                           ms3d_stream_t stream);
+/* The same sum in a FIXED order (bit-reproducible; the float atomics of ms3d_scatter_add_rows add in arrival order, which
+ * is only harmless while no destination row has more than two sources): keys_sorted = idx sorted ascending by a STABLE
+ * sort, order[p] = the source row at sorted position p.  dst pre-zeroed by the caller; one writer per destination row. */
+int ms3d_scatter_add_rows_sorted(const float *src, const long long *keys_sorted, const long long *order, long n, int C,
+                                 float *dst, ms3d_stream_t stream);
 
 /* ---- IoU family: replace get_iou_cuda (get_iou/get_iou.h:16, get_iou.cu:12-38) and
  * get_mask_iou_on_cluster_cuda / get_mask_iou_on_pred_cuda / get_mask_label_cuda
@@ -263,8 +268,10 @@ int ms3d_spconv_prep_weights_multi(const void *descs, int n, int total_blocks, m
 int ms3d_bn_finalize(const float *partial, int nparts, long V, int C, float eps, float momentum, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, float *mean, float *invstd,
                      float *scale, float *shift, ms3d_stream_t stream);
-/* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs
- * (partial_ws: ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout floats) reduced in a fixed order. */
+/* dW[k] = sum_i act(in[nbr[k][i],:])^T dout[i,:].  Deterministic: per-row-chunk partial slabs reduced in a fixed
+ * order.  partial_ws MUST hold ms3d_spconv_wgrad_ws_floats(Vout, K, Cin, Cout) floats: the slab count depends on the
+ * kernel that serves the shape (K = 1 heads: up to 1024 slabs; bf16x3 layers: the operand images behind the slabs).
+ * ms3d_spconv_wgrad_row_chunks(Vout) * K*Cin*Cout is only a LOWER bound (the f32 table walk's slab count). */
 int ms3d_spconv_wgrad_row_chunks(int Vout);
 /* floats of partial_ws a backward-weight call may use (slabs; wide K = 27 layers add the three-piece bf16 images of both
  * operands).  K = 27 is the SUBMANIFOLD case: `in` and `dout` have the same Vout rows -- a 27-offset table whose input row

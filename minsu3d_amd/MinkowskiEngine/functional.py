@@ -51,6 +51,24 @@ class GroupFlushFn(torch.autograd.Function):
         return (None,) + grads
 
 
+def _defer_of(W, tok):
+    """The deferred-reduction stamp of a kernel alias for this forward (prepare_conv_weights) -> (queue, use counter) or
+    None, counting this use.  The deferral hands autograd a dW that is only filled when the group's GroupFlushFn node
+    runs, which is sound while nothing computes on dW in between: a SECOND convolution on the same alias in one forward
+    (weight sharing, a module called in a loop) makes autograd's input buffer add the two still-unwritten tensors before
+    the flush.  The decision is therefore taken at BACKWARD time, when the count is final: `_queue`."""
+    d = getattr(W, "_ms3d_defer", None)
+    if d is None or d[1] != tok:
+        return None
+    d[2][0] += 1
+    return (d[0], d[2])
+
+
+def _queue(defer):
+    """the queue a backward may defer to: only when its kernel alias was used exactly once in the forward"""
+    return defer[0] if (defer is not None and defer[1][0] == 1) else None
+
+
 class SparseConvFn(torch.autograd.Function):
     """(y, stats) = conv(act(x)) [+ residual];  stats = per-block (sum, sum of squares) of y from the kernel epilogue
     (non-differentiable side output that lets the next BatchNorm skip its statistics pass)"""
@@ -70,8 +88,7 @@ class SparseConvFn(torch.autograd.Function):
             stats = x.new_zeros(0)
         ctx.spec, ctx.bn, ctx.wf_buf, ctx.has_res = spec, bn, wf_buf, residual is not None
         # (deferred slab reduction: the queue of this kernel's group, stamped by prepare_conv_weights for this forward)
-        defer = getattr(W, "_ms3d_defer", None)
-        ctx.defer = defer[0] if (defer is not None and defer[1] == getattr(be, "weight_token", None)) else None
+        ctx.defer = _defer_of(W, getattr(be, "weight_token", None))
         ctx.w_direct = W.is_leaf or ctx.defer is not None    # nobody computes on dW before the parameter / the flush node
         if skip is not None:     # None | ("head", SkipLink) | ("tail", SkipLink)
             if skip[0] == "head":
@@ -106,8 +123,8 @@ class SparseConvFn(torch.autograd.Function):
         else:
             fused = add is not None and ctx.needs_input_grad[0] and be.fuses_dx_add(bn)
             extra = {"dx_add": add} if fused else {}
-            if ctx.defer is not None:
-                extra["defer"] = ctx.defer
+            if _queue(ctx.defer) is not None:
+                extra["defer"] = _queue(ctx.defer)
             elif (not ctx.w_direct or (W.is_leaf and W.grad is not None)) and hasattr(be, "wgrad_stream_mode") \
                     and be.wgrad_stream_mode() == 2:
                 # MS3D_WGRAD_STREAM=2 only: dW is consumed on this stream right away (a slice of a padded kernel's
@@ -156,8 +173,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.spec, ctx.wf = spec, (wf1, wf2)
         ctx.bn = (dict(scale=s0, shift=h0, mean=m0, invstd=i0, relu=True, training=True),
                   dict(scale=s1, shift=h1, mean=m1, invstd=i1, relu=True, training=True))
-        d1, d2 = getattr(W1, "_ms3d_defer", None), getattr(W2, "_ms3d_defer", None)
-        ctx.defer = (d1[0] if (d1 is not None and d1[1] == tok) else None, d2[0] if (d2 is not None and d2[1] == tok) else None)
+        ctx.defer = (_defer_of(W1, tok), _defer_of(W2, tok))
         ctx.save_for_backward(x, y1, W1, W2)
         if st2 is None:
             st2 = x.new_zeros(0)
@@ -172,9 +188,9 @@ class ResBlockFn(torch.autograd.Function):
         x, y1, W1, W2 = ctx.saved_tensors
         dy = dy.contiguous()
         V, c0, c1 = spec.vout, spec.cin, spec.cout
-        e2 = {"defer": ctx.defer[1]} if ctx.defer[1] is not None else {}
+        e2 = {"defer": _queue(ctx.defer[1])} if _queue(ctx.defer[1]) is not None else {}
         dx1, dgb1, dW2 = be.conv_layer_backward(y1, dy, ctx.wf[1], spec.nbr_fwd, spec.nbr_bwd, V, V, 27, c1, c1, ctx.bn[1], True, **e2)
-        e1 = {"defer": ctx.defer[0]} if ctx.defer[0] is not None else {}
+        e1 = {"defer": _queue(ctx.defer[0])} if _queue(ctx.defer[0]) is not None else {}
         dx, dgb0, dW1 = be.conv_layer_backward(x, dx1, ctx.wf[0], spec.nbr_fwd, spec.nbr_bwd, V, V, 27, c0, c1, ctx.bn[0],
                                                ctx.needs_input_grad[0], dx_add=dy, **e1)
         return dx, dW1.view_as(W1), dgb0[1], dgb0[0], dW2.view_as(W2), dgb1[1], dgb1[0], None, None, None, None, None
@@ -216,11 +232,7 @@ class ResBlockDownFn(torch.autograd.Function):
                        training=True),
                   dict(scale=s1, shift=h1, mean=m1, invstd=i1, relu=True, training=True))
 
-        def queue(W):
-            d = getattr(W, "_ms3d_defer", None)
-            return d[0] if (d is not None and d[1] == tok) else None
-
-        ctx.defer = (queue(Wd), queue(W1), queue(W2))
+        ctx.defer = (_defer_of(Wd, tok), _defer_of(W1, tok), _defer_of(W2, tok))
         ctx.save_for_backward(x, y1, Wd, W1, W2)
         ctx.mark_non_differentiable(st2)
         ctx.set_materialize_grads(False)
@@ -233,7 +245,7 @@ class ResBlockDownFn(torch.autograd.Function):
         x, y1, Wd, W1, W2 = ctx.saved_tensors
         dy = dy.contiguous()
         V, cin, cout = spec.vout, spec.cin, spec.cout
-        ex = lambda q: ({"defer": q} if q is not None else {})
+        ex = lambda d: ({"defer": _queue(d)} if _queue(d) is not None else {})
         dx1, dgb1, dW2 = be.conv_layer_backward(y1, dy, ctx.wf[2], spec.nbr_fwd, spec.nbr_bwd, V, V, 27, cout, cout, ctx.bn[1],
                                                 True, **ex(ctx.defer[2]))
         need = ctx.needs_input_grad[0]
@@ -267,8 +279,7 @@ class BnReluConvFn(torch.autograd.Function):
         ctx.spec, ctx.wf = spec, wf
         ctx.bn = dict(scale=s0.contiguous(), shift=h0.contiguous(), mean=m0.contiguous(), invstd=i0.contiguous(), relu=True,
                       training=True)
-        d = getattr(W, "_ms3d_defer", None)
-        ctx.defer = d[0] if (d is not None and d[1] == tok) else None
+        ctx.defer = _defer_of(W, tok)
         ctx.save_for_backward(x, W)
         if st is None:
             st = x.new_zeros(0)
@@ -281,7 +292,7 @@ class BnReluConvFn(torch.autograd.Function):
         be = get_backend()
         spec = ctx.spec
         x, W = ctx.saved_tensors
-        e = {"defer": ctx.defer} if ctx.defer is not None else {}
+        e = {"defer": _queue(ctx.defer)} if _queue(ctx.defer) is not None else {}
         dx, dgb, dW = be.conv_layer_backward(x, dy.contiguous(), ctx.wf, spec.nbr_fwd, spec.nbr_bwd, spec.vin, spec.vout, spec.K,
                                              spec.cin, spec.cout, ctx.bn, ctx.needs_input_grad[0], **e)
         return dx, dW.view_as(W), dgb[1], dgb[0], None, None, None, None
@@ -369,16 +380,32 @@ class GatherRowsFn(torch.autograd.Function):
     """y = x[idx] with a many-to-one index (voxel -> points).  torch's backward (index_put_ with accumulate) sorts the
     indices on every call; here the backward is one scatter-add kernel."""
 
+    PRESORT_MIN_ROWS = 1 << 16
+
     @staticmethod
-    def forward(ctx, x, idx):
+    def forward(ctx, x, idx, max_dup=None):
         ctx.save_for_backward(idx)
-        ctx.n_rows = x.size(0)
+        ctx.n_rows, ctx.max_dup, ctx.sorted = x.size(0), max_dup, None
+        be = get_backend()
+        if idx.is_cuda and (max_dup is None or max_dup > 2) and hasattr(be, "presort_rows") and be.deterministic():
+            # the backward sums in a fixed order over a stable sort of idx: take the one the loader's prefetch left on the
+            # tensor, or queue it now on the helper thread / side stream
+            cached = getattr(idx, "_ms3d_sorted", None)
+            if cached is not None and cached[2] == idx._version:
+                ctx.sorted = cached[:2]
+            elif idx.numel() >= GatherRowsFn.PRESORT_MIN_ROWS:
+                ctx.sorted = be.presort_rows(idx)
         return _rows(x, idx)
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
-        return get_backend().scatter_add_rows(dy.contiguous(), idx, ctx.n_rows), None
+        extra = {}
+        if ctx.max_dup is not None:
+            extra["max_dup"] = ctx.max_dup
+        if ctx.sorted is not None:
+            extra["sorted_"] = ctx.sorted
+        return get_backend().scatter_add_rows(dy.contiguous(), idx, ctx.n_rows, **extra), None, None
 
 
 class PermuteRowsFn(torch.autograd.Function):
@@ -395,8 +422,9 @@ class PermuteRowsFn(torch.autograd.Function):
         return _rows(dy, perm), None, None
 
 
-def gather_rows(x, idx):
-    """differentiable x[idx] for 2-D float features and an int64 row index"""
+def gather_rows(x, idx, max_dup=None):
+    """differentiable x[idx] for 2-D float features and an int64 row index.  max_dup: the caller's bound on how many
+    entries of idx name the same row (<= 2: the backward's float atomics are order-independent, no sort needed)"""
     if x.dim() == 2 and idx.dim() == 1 and idx.dtype == torch.int64 and x.requires_grad:
-        return GatherRowsFn.apply(x, idx)
+        return GatherRowsFn.apply(x, idx, max_dup)
     return _rows(x, idx) if x.dim() == 2 and idx.dim() == 1 else x[idx]

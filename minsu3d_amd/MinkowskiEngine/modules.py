@@ -100,7 +100,7 @@ def prepare_conv_weights(root):
             eff = Fn.GroupFlushFn.apply(queue, *[w for w, _, _ in members])
             for e, (w, buf, m) in zip(eff, members):
                 e._ms3d_wf = (buf, token)
-                e._ms3d_defer = (queue, token)
+                e._ms3d_defer = (queue, token, [0])      # [uses of this alias in the forward]: functional._defer_of
                 m.__dict__["_kernel_eff"] = (e, token)
     for w, buf, *_ in layers:
         w._ms3d_wf = (buf, token)

@@ -96,7 +96,7 @@ def _iota(n, device):
 _PREFETCHED = {}   # (data_ptr, shape) of a coordinate tensor -> (future of (manager, cuda event), the tensor itself)
 
 
-def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channels=None):
+def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channels=None, point_map=None):
     """Input pipelining (not part of ME's API): build everything that depends on the COORDINATES of a batch the next
     forward will use -- engine row order, the coordinate sets and kernel maps of `n_levels` U-Net levels, their pair
     lists -- on the helper thread and a side stream, e.g. while the current step's backward pass keeps the GPU busy and
@@ -104,7 +104,8 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channe
     wait_current_stream=False: the coordinates are known to be complete (a resident batch), the side stream need not
     wait for the work queued on the caller's stream.  channels: the channel width of every level (the pair list a
     convolution walks depends on it: 128-row tiles above 32 channels); without it the 16 / 32-channel lists are built and
-    a wider level builds its own on first use."""
+    a wider level builds its own on first use.  point_map: the batch's voxel_point_map -- its stable sort (the fixed
+    summation order of the voxel -> point broadcast's backward, backend.sorted_rows) is built here too."""
     if not coordinates.is_cuda or os.environ.get("MS3D_PREFETCH_COORDS", "1") == "0":
         return
     key = (coordinates.data_ptr(), tuple(coordinates.shape))
@@ -138,6 +139,8 @@ def prefetch_coordinates(coordinates, n_levels, wait_current_stream=True, channe
                 # prefetch stream, instead of by two torch launches per table inside a sampled (timed) step
                 for t in list(cm._k3.values()) + [x for pair in cm._k2.values() for x in pair]:
                     t._ms3d_pairs_dev = (t >= 0).sum()
+            if point_map is not None and point_map.is_cuda and point_map.dtype == torch.int64 and be.deterministic():
+                cm._aux_tensors = list(be.sorted_rows(point_map))
             ev = torch.cuda.Event()
             ev.record(side)
             return cm, ev
@@ -158,6 +161,7 @@ def _take_prefetched(coordinates):
     cur.wait_event(ev)
     # everything was allocated under the side stream and is used (and eventually freed) under this one
     held = [cm.perm, cm.inv] + list(cm.coords.values()) + list(cm._k3.values()) + [t for pair in cm._k2.values() for t in pair]
+    held.extend(getattr(cm, "_aux_tensors", ()))
     ext = getattr(cm, "coords_external", None)
     if ext is not None and ext is not coordinates:
         held.append(ext)     # an int32 copy made on the side stream (the caller's coordinates had another dtype)

@@ -367,14 +367,66 @@ class HipBackend:
                                              _lib.stream_handle()), "ms3d_gather_rows")
         return out
 
-    def scatter_add_rows(self, src, idx, n_rows):
-        """dst[idx[i]] += src[i] -> dst [n_rows, C]; float atomics (order-dependent rounding, within fp32 noise)"""
+    def sorted_rows(self, idx):
+        """(keys, order) of a STABLE ascending sort of an int64 row index, cached on the tensor: what the fixed-order
+        scatter-add needs.  Callers that know the index ahead of its backward (the loader's voxel_point_map) call this
+        early, off the critical path; torch's radix sort (rocPRIM) is plumbing, not a hot kernel."""
+        cached = getattr(idx, "_ms3d_sorted", None)
+        if cached is None or cached[2] != idx._version:
+            keys, order = torch.sort(idx, stable=True)
+            cached = idx._ms3d_sorted = (keys, order, idx._version)
+        return cached[0], cached[1]
+
+    def presort_rows(self, idx):
+        """Scheduling only: the stable sort of `idx` queued on the helper thread and the side stream NOW (the forward of
+        a row gather: ~200 us of radix sort for 800k rows that the backward would otherwise wait for on the critical
+        path) -> a handle for scatter_add_rows(sorted_=...)"""
+        main = torch.cuda.current_stream(idx.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = side_stream(idx.device)
+
+        def job():
+            with torch.cuda.stream(side), torch.no_grad():
+                side.wait_event(ready)
+                keys, order = torch.sort(idx, stable=True)
+                done = torch.cuda.Event()
+                done.record(side)
+                return keys, order, done
+        return (worker().submit(job), side)
+
+    def scatter_add_rows(self, src, idx, n_rows, max_dup=None, sorted_=None):
+        """dst[idx[i]] += src[i] -> dst [n_rows, C], bit-reproducible: rows that may collect more than two sources are
+        summed in ascending source order over a stable sort of the index (ms3d_scatter_add_rows_sorted); max_dup <= 2
+        (the caller knows no row has more than two sources: a + b = b + a exactly) keeps the one-launch float atomics,
+        as does MS3D_DETERMINISTIC=0.  sorted_: (keys, order) of that sort, or a presort_rows handle."""
         src = self._dev(src); idx = self._dev(idx)
         assert idx.dtype == torch.int64
         dst = torch.zeros((n_rows, src.size(1)), dtype=torch.float32, device=src.device)
-        _lib.check(self.lib.ms3d_scatter_add_rows(_lib.ptr(src), _lib.ptr(idx), C.c_long(src.size(0)), int(src.size(1)),
-                                                  _lib.ptr(dst), _lib.stream_handle()), "ms3d_scatter_add_rows")
+        if (max_dup is not None and max_dup <= 2) or not self.deterministic():
+            _lib.check(self.lib.ms3d_scatter_add_rows(_lib.ptr(src), _lib.ptr(idx), C.c_long(src.size(0)), int(src.size(1)),
+                                                      _lib.ptr(dst), _lib.stream_handle()), "ms3d_scatter_add_rows")
+            return dst
+        if sorted_ is not None and not torch.is_tensor(sorted_[0]):
+            keys, order, done = sorted_[0].result()
+            cur = torch.cuda.current_stream(src.device)
+            cur.wait_event(done)
+            keys.record_stream(cur); order.record_stream(cur); idx.record_stream(sorted_[1])
+        elif sorted_ is not None:
+            keys, order = sorted_
+        else:
+            keys, order = self.sorted_rows(idx)
+        _lib.check(self.lib.ms3d_scatter_add_rows_sorted(_lib.ptr(src), _lib.ptr(keys), _lib.ptr(order),
+                                                         C.c_long(src.size(0)), int(src.size(1)), _lib.ptr(dst),
+                                                         _lib.stream_handle()), "ms3d_scatter_add_rows_sorted")
         return dst
+
+    def deterministic(self):
+        """MS3D_DETERMINISTIC (default 1): every float sum of a training step in a fixed order"""
+        on = self.__dict__.get("_deterministic")
+        if on is None:
+            on = self._deterministic = os.environ.get("MS3D_DETERMINISTIC", "1") != "0"
+        return on
 
     # ------------------------------------------------------------------ per-point losses
     def point_losses_forward(self, scores, labels, pred_offsets, centre, xyz, instance_ids):
@@ -555,7 +607,7 @@ class WgradQueue:
     layers' dW tensors are handed to autograd unreduced; the flush fills them in before anybody downstream (gradient
     accumulation, a data-parallel wrapper's bucket hooks, the optimizer) sees them.  Summation order per element is the
     per-layer kernels': bit-identical gradients."""
-    _host = _host_np = _dev = None      # descriptor staging, shared by all queues of the process (one device per process)
+    _host = _host_np = _dev = _copied = None   # descriptor staging, shared by all queues of the process (one device per process)
     _turn = 0
     RING = 16                           # pinned staging slots: a slot is rewritten 16 flushes (~4 steps) later
 
@@ -588,13 +640,18 @@ class WgradQueue:
         rows = 4 * len(launches) + len(items)            # in 32-byte rows
         cls = WgradQueue
         if cls._host is None or cls._host[0].shape[0] < rows or cls._dev[0].device != dev:
-            cap = max(2 * rows, 512)
+            cap = (max(2 * rows, 512) + 3) & ~3          # whole 128-byte rows
             cls._host = [torch.empty((cap, 4), dtype=torch.int64).pin_memory() for _ in range(self.RING)]
             cls._host_np = [h.numpy().view(np.uint64) for h in cls._host]
             cls._dev = [torch.empty((cap, 4), dtype=torch.int64, device=dev) for _ in range(self.RING)]
+            cls._copied = [None] * self.RING
         turn = cls._turn
         cls._turn = (turn + 1) % self.RING
         hn, tdev = cls._host_np[turn], cls._dev[turn]
+        if cls._copied[turn] is not None:
+            # the slot's previous host->device copy must have executed before the pinned buffer is rewritten: a host that
+            # runs more than RING flushes (~4 steps) ahead of the GPU would otherwise corrupt a queued table
+            cls._copied[turn].synchronize()
         h32 = hn.view(np.int32).reshape(-1, 32)          # the same bytes as 128-byte rows
         plan, row = [], 0
         for variant, group in by_variant.items():
@@ -615,6 +672,10 @@ class WgradQueue:
             hn[r0 + i, 3] = (nblk & 0xffffffff) | (((begin_r | (0x80000000 if wide else 0)) & 0xffffffff) << 32)
             begin_r += blocks
         tdev[:rows].copy_(cls._host[turn][:rows], non_blocking=True)
+        ev = cls._copied[turn]
+        if ev is None:
+            ev = cls._copied[turn] = torch.cuda.Event()
+        ev.record()
         base = tdev.data_ptr()
         for variant, first, n_desc, total, timing in plan:
             ev = self.timer.conv_group("wgrad", timing) if (self.timer is not None and timing) else None

@@ -6,6 +6,7 @@
 // ~24 scans x 3 per training step, most of them inside the ball-query / clustering chains.
 // Used by the ball query (cell starts, list starts), the BFS output assembly and the coordinate engine.
 #include <stdlib.h>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 
@@ -178,17 +179,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const int *i
 }
 
 // the look-back state of a stream (scans on one stream are ordered, scans on different streams run concurrently)
+// Keyed by (device, stream): the default stream's handle is the same on every device, and the state lives in the memory
+// of the device that was current when it was made.
 ScanState *scan_state(hipStream_t stream)
 {
     static std::mutex lock;
-    static std::unordered_map<hipStream_t, ScanState *> states;
+    static std::map<std::pair<int, hipStream_t>, ScanState *> states;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> guard(lock);
-    auto it = states.find(stream);
+    auto it = states.find({dev, stream});
     if (it != states.end()) return it->second;
     ScanState *p = nullptr;
     if (hipMalloc((void **)&p, sizeof(ScanState)) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, sizeof(ScanState)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    states.emplace(stream, p);
+    states.emplace(std::make_pair(dev, stream), p);
     return p;
 }
 

@@ -328,6 +328,61 @@ __global__ void scatter_add_rows_kernel(const float *__restrict__ src, const lon
     atomicAdd(&dst[(size_t)idx[i] * C + c], src[t]);
 }
 
+// The same backward with a FIXED summation order (round 5: bit-reproducible training steps).  keys = the index list
+// sorted ascending by a STABLE sort, order = the source row of every sorted position: the first position of a run of
+// equal keys adds the run's rows up in list order (= ascending source row) and is the only writer of its destination
+// row; rows no key names keep the caller's zeros.  Four gathers in flight per thread (a run is a chain of dependent
+// round trips otherwise).  VEC = 4: C % 4 == 0, 16 bytes per lane.
+template <int VEC>
+__global__ void segment_sum_sorted_kernel(const float *__restrict__ src, const long long *__restrict__ keys,
+                                          const long long *__restrict__ order, long n, int CQ, float *__restrict__ dst)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * CQ) return;
+    const long p = t / CQ;
+    const int c = (int)(t - p * CQ);
+    const long long key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;
+    float acc[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; u++) acc[u] = 0.f;
+    long q = p;
+    while (q < n) {
+        long long k[4], o[4];
+        float v[4][VEC];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const long qq = q + j < n ? q + j : n - 1;
+            k[j] = q + j < n ? keys[qq] : -1;
+            o[j] = order[qq];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (VEC == 4) {
+                const float4 r = reinterpret_cast<const float4 *>(src)[o[j] * CQ + c];
+                v[j][0] = r.x; v[j][1 % VEC] = r.y; v[j][2 % VEC] = r.z; v[j][3 % VEC] = r.w;
+            } else {
+                v[j][0] = src[o[j] * CQ + c];
+            }
+        }
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (k[j] != key) done = true;
+            if (!done) {
+#pragma unroll
+                for (int u = 0; u < VEC; u++) acc[u] += v[j][u];
+            }
+        }
+        if (done) break;
+        q += 4;
+    }
+    if (VEC == 4)
+        reinterpret_cast<float4 *>(dst)[key * CQ + c] = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+    else
+        dst[key * CQ + c] = acc[0];
+}
+
 __global__ void roipool_bp_kernel(int P, int C, float *__restrict__ d_feats, const int *__restrict__ maxidx,
                                   const float *__restrict__ d_out)
 {
@@ -544,6 +599,18 @@ int ms3d_scatter_add_rows(const float *src, const long long *idx, long n, int C,
 {
     if (n <= 0 || C <= 0) return 0;
     scatter_add_rows_kernel<<<ms3d_divup(n * C, 256), 256, 0, (hipStream_t)stream>>>(src, idx, n, C, dst);
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ms3d_scatter_add_rows_sorted(const float *src, const long long *keys_sorted, const long long *order, long n, int C,
+                                 float *dst, ms3d_stream_t stream)
+{
+    if (n <= 0 || C <= 0) return 0;
+    if (C % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0)
+        segment_sum_sorted_kernel<4><<<ms3d_divup(n * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(src, keys_sorted, order, n, C / 4, dst);
+    else
+        segment_sum_sorted_kernel<1><<<ms3d_divup(n * C, 256), 256, 0, (hipStream_t)stream>>>(src, keys_sorted, order, n, C, dst);
     MS3D_LAUNCH_CHECK();
     return 0;
 }

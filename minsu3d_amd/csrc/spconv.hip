@@ -23,6 +23,7 @@
 // the reduction dimension, several offsets per wave sharing the dout fragment.
 #include <stdlib.h>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include "common.h"
@@ -73,6 +74,7 @@ struct ConvArgs {
     int pre_relu;
     const int *pl_tile_start;  // pair list of the table (ms3d_kmap_pairlist_build) or null
     const int *pl_entries;
+    int dyn_picks;             // pair-list kernels: tiles picked off an LDS counter (MS3D_PL_DYNAMIC=1) instead of the fixed schedule
 };
 
 // ------------------------------------------------------------------ weight permutation
@@ -435,8 +437,38 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
     }
 }
 
+// Statistics (round 5: bit-reproducible).  `slot` is the calling wave's OWN [2][NBT*16] area of the block's statistics
+// (stat_slot): plain LDS read-modify-writes -- one writer per slot, a wave's LDS operations execute in order, a wave
+// takes its tiles in a fixed order -- and stats_flush adds the slots up in wave order.  (Rounds 1-4 let all waves
+// atomicAdd into one [2][Cout] area: the order of the float additions, and with it the last bits of every training-mode
+// BatchNorm, changed from run to run.)
+__host__ __device__ constexpr size_t stat_slot_floats(int nbt) { return 2 * (size_t)nbt * 16; }
+constexpr int STAT_MAX_WAVES = 16;   // waves of the largest table-walk workgroup
+
 template <int NBT>
-__device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0, f32x4 (&acc)[NBT], float *s_part)
+__device__ __forceinline__ void stats_clear(float *s_part, int nslots)
+{
+    for (int t = threadIdx.x; t < nslots * (int)stat_slot_floats(NBT); t += blockDim.x) s_part[t] = 0.f;
+}
+
+// after the block's last store_tile: partial row of this block = the slots added in slot order; every blockIdx.y owns its
+// own columns, the others stay zero and are summed away by the finalize kernel
+template <int NBT>
+__device__ __forceinline__ void stats_flush(const ConvArgs &p, const float *s_part, int nslots, int nb0)
+{
+    __syncthreads();
+    float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
+    for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) {
+        const int which = t >= p.Cout, c = t - which * p.Cout - 16 * nb0;  // column inside this block's slice
+        float sum = 0.f;
+        if (c >= 0 && c < NBT * 16)
+            for (int w = 0; w < nslots; w++) sum += s_part[(size_t)w * stat_slot_floats(NBT) + which * NBT * 16 + c];
+        dst[t] = sum;
+    }
+}
+
+template <int NBT>
+__device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0, f32x4 (&acc)[NBT], float *slot)
 {
     const int l = lane_id(), q = l >> 4, jl = l & 15;
 #pragma unroll
@@ -467,12 +499,12 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, int row0, int nb0,
             }
         }
         if (p.bn_x || p.out_stats) {
-            // reduce over the 4 q-groups (same column), then one LDS atomic per column per wave
+            // reduce over the 4 q-groups (same column), then into the wave's own slot (padded columns add zeros)
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (q == 0 && j_ok) {
-                atomicAdd(&s_part[j], s1);
-                atomicAdd(&s_part[p.Cout + j], s2);
+            if (q == 0) {
+                slot[16 * nb + jl] += s1;
+                slot[NBT * 16 + 16 * nb + jl] += s2;
             }
         }
     }
@@ -489,7 +521,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     const int waves = blockDim.x >> 6;
     const int nb0 = blockIdx.y * NBT;
     float *sW = lds;
-    float *s_part = lds + (size_t)p.G * p.NCH * 4 * NBT * 64;  // [2*Cout] when bn_x
+    float *s_part = lds + (size_t)p.G * p.NCH * 4 * NBT * 64;  // [waves] statistics slots when bn_x / out_stats
     const int slab4 = NBT * 16;                                    // float4s per (offset, ch, t) in the LDS image
     // copy offsets [k_lo, k_lo+cnt) of this block's column slice: contiguous NBT*64 floats per (k, ch, t)
     auto stage = [&](int k_lo, int cnt) {
@@ -502,9 +534,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
     };
 
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
-    if (with_partial) {
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
-    }
+    if (with_partial) stats_clear<NBT>(s_part, waves);
+    float *slot = s_part + (size_t)wave_id() * stat_slot_floats(NBT);
     // XCD-aware placement: blocks b, b+8, b+16.. share an XCD (dispatch is round-robin), give them adjacent tiles
     const int nblk = gridDim.x;
     const int per_xcd = (nblk + 7) / 8;
@@ -531,7 +562,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             ConvArgs pt = p;
             asm volatile("" : "+s"(pt.out), "+s"(pt.residual), "+s"(pt.bias), "+s"(pt.bn_x), "+s"(pt.bn_scale), "+s"(pt.bn_shift),
                          "+s"(pt.bn_mean), "+s"(pt.bn_invstd));
-            store_tile<NBT>(pt, row0, nb0, acc, s_part);
+            store_tile<NBT>(pt, row0, nb0, acc, slot);
         }
     } else {
         // weights streamed through LDS in groups of G offsets; one tile per wave, accumulators stay in registers
@@ -548,14 +579,9 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             __syncthreads();
             if (tile < p.ntiles) accumulate_offsets<NBT, ALIGNED>(p, sW, g0, g0 + gn, 0, my_row, q, nb0, acc);
         }
-        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
+        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, slot);
     }
-    if (with_partial) {
-        __syncthreads();
-        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        // each blockIdx.y owns its own columns; others stay zero and are summed away by the finalize kernel
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
-    }
+    if (with_partial) stats_flush<NBT>(p, s_part, waves, nb0);
 }
 
 // ---- table walk on the three-piece bf16 image (wide layers) -----------------------------------------------------
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
     const int GC = p.GC > 0 ? p.GC : NC32;                                  // chunks per stage
     uint4 *sW = reinterpret_cast<uint4 *>(lds);                             // [offset in group][chunk in range][nb][piece][lane] x 16 B
     const int slab = NBT * 3 * 64;                                          // uint4 per (offset, c32) in the LDS image
-    float *s_part = lds + (size_t)p.G * GC * slab * 4;                      // [2*Cout] when statistics are asked for
+    float *s_part = lds + (size_t)p.G * GC * slab * 4;                      // [waves] statistics slots when asked for
     const uint4 *img = reinterpret_cast<const uint4 *>(p.wfb);
     // offsets [k_lo, k_lo + cnt) x chunks [c_lo, c_lo + ccnt) of this block's column slice, copied by
     // global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS at a wave-uniform base -- no registers, a handful of
@@ -600,9 +626,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
         }
     };
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
-    if (with_partial) {
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
-    }
+    if (with_partial) stats_clear<NBT>(s_part, waves);
     const int nblk = gridDim.x;
     const int per_xcd = (nblk + 7) / 8;
     int vb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -701,13 +725,9 @@ __global__ __launch_bounds__(1024) void spconv_fwd_bf3_kernel(ConvArgs p)
 #pragma unroll
             for (int u = 0; u < OG; u++) idx[u] = idx_n[u];
         }
-        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part);
+        if (tile < p.ntiles) store_tile<NBT>(p, row0, nb0, acc, s_part + (size_t)wave_id() * stat_slot_floats(NBT));
     }
-    if (with_partial) {
-        __syncthreads();
-        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
-    }
+    if (with_partial) stats_flush<NBT>(p, s_part, waves, nb0);
 }
 
 // measured per column count (profiles/r03_fwd_experiments.txt section 9)
@@ -736,11 +756,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
     const int waves = blockDim.x >> 6;  // = ceil(K / OG)
     const int nb0 = blockIdx.y * NBT;
     float *s_acc = lds;                                        // [(waves-1)][NBT][4][64]
-    float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // [2*Cout] when bn_x / out_stats
+    float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // one statistics slot (wave 0 finishes every tile) when bn_x / out_stats
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
-    if (with_partial) {
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
-    }
+    if (with_partial) stats_clear<NBT>(s_part, 1);
     // p.RT > 1: the geometry was laid out for the bf16x3 RT-tile kernel but this call has no bf16x3 image (the exact-f32
     // entry point on a wide layer): the same blocks take their RT tiles one after the other
     const int rt = p.RT > 1 ? p.RT : 1;
@@ -770,11 +788,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
             store_tile<NBT>(p, row0, nb0, acc, s_part);
         }
     }
-    if (with_partial) {
-        __syncthreads();
-        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
-    }
+    if (with_partial) stats_flush<NBT>(p, s_part, 1, nb0);
 }
 
 // ---- small levels on the three-piece bf16 image: one block per (tile, column slice), its waves split the K offsets,
@@ -794,9 +808,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
     float *s_acc = lds;                                        // [(waves-1)][NBT][4][64]
     float *s_part = lds + (size_t)(waves - 1) * NBT * 256;     // [2*Cout] when bn_x / out_stats
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
-    if (with_partial) {
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
-    }
+    if (with_partial) stats_clear<NBT>(s_part, 1);      // wave 0 finishes the tile: one slot
     const int tile = blockIdx.x;
     const int row0 = tile * 16, my_row = row0 + (l & 15);
     const bool row_ok = my_row < p.Vout;
@@ -891,11 +903,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_kernel(ConvArgs p)
                 for (int r = 0; r < 4; r++) acc[nb][r] += s_acc[((size_t)(w - 1) * NBT + nb) * 256 + r * 64 + l];
         store_tile<NBT>(p, row0, nb0, acc, s_part);
     }
-    if (with_partial) {
-        __syncthreads();
-        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
-    }
+    if (with_partial) stats_flush<NBT>(p, s_part, 1, nb0);
 }
 
 // ---- the same with RT row tiles per block (levels of ~3k - 17k rows) ------------------------------------------
@@ -915,11 +923,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_rt_kernel(ConvArgs p
     const int nb0 = blockIdx.y * NBT;
     const int NC32 = (p.Cin + 31) >> 5;
     float *s_acc = lds;                                             // [waves][RT][NBT][4][64]
-    float *s_part = lds + (size_t)waves * RT * NBT * 256;          // [2*Cout] when bn_x / out_stats
+    float *s_part = lds + (size_t)waves * RT * NBT * 256;          // [waves] statistics slots when bn_x / out_stats
     const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
-    if (with_partial) {
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) s_part[t] = 0.f;
-    }
+    if (with_partial) stats_clear<NBT>(s_part, waves);  // wave t finishes tile t: a slot per wave
     const int tile0 = blockIdx.x * RT;
     int safe_row[RT];
     bool row_ok[RT];
@@ -1051,13 +1057,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_bf3_rt_kernel(ConvArgs p
             for (int nb = 0; nb < NBT; nb++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) sum[nb][r] += s_acc[(((size_t)ww * RT + t) * NBT + nb) * 256 + r * 64 + l];
-        store_tile<NBT>(p, (tile0 + t) * 16, nb0, sum, s_part);
+        store_tile<NBT>(p, (tile0 + t) * 16, nb0, sum, s_part + (size_t)w * stat_slot_floats(NBT));
     }
-    if (with_partial) {
-        __syncthreads();
-        float *dst = p.bn_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * p.Cout;
-        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) dst[t] = s_part[t];
-    }
+    if (with_partial) stats_flush<NBT>(p, s_part, waves, nb0);
 }
 
 template <int NBT, int RT>
@@ -1085,7 +1087,7 @@ int launch_fwd_small(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool
     // >= 96 output channels) while this call has no bf16x3 image (the exact-f32 entry point, a BatchNorm without ReLU,
     // aux kind 1): this kernel parks (waves - 1) x nbt accumulator tiles + the statistics only -- ask for that, not for
     // the other kernel's footprint (which would exceed the 64 KB a kernel gets without raising its ceiling)
-    const size_t need = ((size_t)(threads / 64 - 1) * NBT * 256 + ((p.bn_x || p.out_stats) ? 2 * (size_t)p.Cout : 0)) * sizeof(float) + 16;
+    const size_t need = ((size_t)(threads / 64 - 1) * NBT * 256 + ((p.bn_x || p.out_stats) ? stat_slot_floats(NBT) : 0)) * sizeof(float) + 16;
     if (lds > need) lds = need;
     if (aligned)
         spconv_fwd_small_kernel<NBT, true><<<grid, threads, lds, stream>>>(p);
@@ -1215,9 +1217,20 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         pre_sh[ch] = p.pre_scale ? *reinterpret_cast<const f32x4 *>(p.pre_shift + 16 * ch + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+    int round = 0;
     while (slot < nmine) {
-        int next_slot = 0;
-        if (l == 0) next_slot = atomicAdd(s_next, 1);  // consumed right below: the next pick's descriptor is requested now
+        // The wave's next tile (its descriptor is requested now).  Round 5: a FIXED schedule -- the part's tiles are listed
+        // longest first; round r hands tiles r*W .. r*W + W - 1 to the waves in alternating direction (the wave that got the
+        // shortest tile of a round gets the longest of the next: what the LDS pick counter of rounds 1-4 did whenever a tile's
+        // time followed its batch count), so the tiles a wave sums its statistics over, and their order, no longer depend on
+        // timing: the epilogue statistics are bit-reproducible.  MS3D_PL_DYNAMIC=1 restores the counter (A/B measurements).
+        ++round;
+        int next_slot = round * waves + ((round & 1) ? waves - 1 - wave_id() : wave_id());
+        if (p.dyn_picks) {
+            int pick = 0;
+            if (l == 0) pick = atomicAdd(s_next, 1);
+            next_slot = pick;
+        }
         const int tile = __builtin_amdgcn_readfirstlane(desc.x);
         const int row0 = tile * CR;
         const int b_begin = __builtin_amdgcn_readfirstlane(desc.y);
@@ -1503,9 +1516,16 @@ __global__ __launch_bounds__(512) void spconv_fwd_pairstream_kernel(ConvArgs p)
     const int c4 = l % F4, col = 16 * nb0 + 4 * c4;
     const bool ep_lane = l < RPS * F4;
 
+    int round = 0;
     while (slot < nmine) {
-        int next_slot = 0;
-        if (l == 0) next_slot = atomicAdd(s_next, 1);
+        // fixed schedule (see spconv_fwd_pairlist_kernel): bit-reproducible statistics; MS3D_PL_DYNAMIC=1 = the pick counter
+        ++round;
+        int next_slot = round * waves + ((round & 1) ? waves - 1 - wave_id() : wave_id());
+        if (p.dyn_picks) {
+            int pick = 0;
+            if (l == 0) pick = atomicAdd(s_next, 1);
+            next_slot = pick;
+        }
         const int tile = __builtin_amdgcn_readfirstlane(desc.x);
         const int row0 = tile * PSR;
         const int b_begin = __builtin_amdgcn_readfirstlane(desc.y);
@@ -2566,52 +2586,68 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(const float *__
     }
 }
 
-// per-block partial (sum, sum of squares) per channel.  Each thread streams float4s (C % 4 == 0) of the block's
-// contiguous row range: fully coalesced 16 B/lane, 4 loads in flight per thread.
+// per-block partial (sum, sum of squares) per channel.  Round 5, bit-reproducible: a thread owns ONE column group (VEC
+// = 4 channels, 16 bytes per lane, when C % 4 == 0; one channel otherwise) of every rpp-th row of the block's row range --
+// thread t = (row in pass) * CQ + (column group), so the threads of a pass read one contiguous stretch -- sums in
+// registers, parks its sums in LDS, and 2C threads add the rpp copies of their column up in row order.  (Rounds 1-4 added
+// into one [2][C] LDS area with float atomics: the order of the additions changed from run to run.)
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float *__restrict__ x, long V, int C,
                                                                float *__restrict__ partial, int rows_per_block)
 {
-    extern __shared__ float s_acc[];  // [2][C]
-    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) s_acc[t] = 0.f;
-    __syncthreads();
+    __shared__ float s_red[256 * 8];  // [thread][2][VEC]
+    const int CQ = C / VEC, rpp = 256 / CQ, tid = threadIdx.x;   // CQ <= 256 (launcher)
+    const bool active = tid < rpp * CQ;
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(V, r_begin + rows_per_block);
-    const long e_begin = r_begin * C, e_end = r_end * C;
-    if ((C & 3) == 0) {
-        const long v_begin = e_begin >> 2, v_end = e_end >> 2;
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-        if ((4 * 256) % C == 0) {
-            // the channel group of a thread never changes: accumulate in registers
-            const int c = (int)((4 * (v_begin + threadIdx.x)) % C);
-            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; u++) s1[u] = s2[u] = 0.f;
+    if (active) {
+        const long stride = (long)rpp * CQ;
+        const long e_end = r_end * CQ;
+        if (VEC == 4) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(x);
 #pragma unroll 4
-            for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
-                const float4 t = x4[v];
-                s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
-                s2.x = fmaf(t.x, t.x, s2.x); s2.y = fmaf(t.y, t.y, s2.y); s2.z = fmaf(t.z, t.z, s2.z); s2.w = fmaf(t.w, t.w, s2.w);
+            for (long e = r_begin * CQ + tid; e < e_end; e += stride) {
+                const float4 t = x4[e];
+                s1[0] += t.x; s1[1 % VEC] += t.y; s1[2 % VEC] += t.z; s1[3 % VEC] += t.w;
+                s2[0] = fmaf(t.x, t.x, s2[0]); s2[1 % VEC] = fmaf(t.y, t.y, s2[1 % VEC]);
+                s2[2 % VEC] = fmaf(t.z, t.z, s2[2 % VEC]); s2[3 % VEC] = fmaf(t.w, t.w, s2[3 % VEC]);
             }
-            atomicAdd(&s_acc[c + 0], s1.x); atomicAdd(&s_acc[c + 1], s1.y); atomicAdd(&s_acc[c + 2], s1.z); atomicAdd(&s_acc[c + 3], s1.w);
-            atomicAdd(&s_acc[C + c + 0], s2.x); atomicAdd(&s_acc[C + c + 1], s2.y); atomicAdd(&s_acc[C + c + 2], s2.z); atomicAdd(&s_acc[C + c + 3], s2.w);
         } else {
-#pragma unroll 2
-            for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
-                const float4 t = x4[v];
-                const int c = (int)((4 * v) % C);
-                atomicAdd(&s_acc[c + 0], t.x); atomicAdd(&s_acc[c + 1], t.y); atomicAdd(&s_acc[c + 2], t.z); atomicAdd(&s_acc[c + 3], t.w);
-                atomicAdd(&s_acc[C + c + 0], t.x * t.x); atomicAdd(&s_acc[C + c + 1], t.y * t.y);
-                atomicAdd(&s_acc[C + c + 2], t.z * t.z); atomicAdd(&s_acc[C + c + 3], t.w * t.w);
+#pragma unroll 4
+            for (long e = r_begin * CQ + tid; e < e_end; e += stride) {
+                const float t = x[e];
+                s1[0] += t;
+                s2[0] = fmaf(t, t, s2[0]);
             }
-        }
-    } else {
-        for (long e = e_begin + threadIdx.x; e < e_end; e += 256) {
-            const float v = x[e];
-            const int c = (int)(e % C);
-            atomicAdd(&s_acc[c], v);
-            atomicAdd(&s_acc[C + c], v * v);
         }
     }
+#pragma unroll
+    for (int u = 0; u < VEC; u++) {
+        s_red[tid * 2 * VEC + u] = s1[u];
+        s_red[tid * 2 * VEC + VEC + u] = s2[u];
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];
+    for (int t = tid; t < 2 * C; t += 256) {
+        const int which = t >= C, c = t - which * C, cq = c / VEC, u = c - cq * VEC;
+        float sum = 0.f;
+        for (int j = 0; j < rpp; j++) sum += s_red[(j * CQ + cq) * 2 * VEC + which * VEC + u];
+        partial[(size_t)blockIdx.x * 2 * C + t] = sum;
+    }
+}
+
+static int launch_bn_partial_stats(const float *x, long V, int C, float *partial, int nblk, int rows_per_block, hipStream_t stream)
+{
+    if ((C & 3) == 0 && C <= 1024)
+        bn_partial_stats_kernel<4><<<nblk, 256, 0, stream>>>(x, V, C, partial, rows_per_block);
+    else if (C <= 256)
+        bn_partial_stats_kernel<1><<<nblk, 256, 0, stream>>>(x, V, C, partial, rows_per_block);
+    else
+        return MS3D_E_UNSUPPORTED;
+    MS3D_LAUNCH_CHECK();
+    return 0;
 }
 
 // y = x*scale + shift (optionally ReLU): the stand-alone BN(+ReLU) at the end of the U-Net
@@ -2664,7 +2700,10 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *_
     }
 }
 
-// stand-alone BN(+ReLU) backward, stage 1: dz = dy * [relu mask]; partial sums of dz and dz*xhat
+// stand-alone BN(+ReLU) backward, stage 1: dz = dy * [relu mask]; partial sums of dz and dz*xhat.  Thread layout and the
+// fixed-order combination of bn_partial_stats_kernel (bit-reproducible; sums in registers -- two LDS atomics per ELEMENT
+// made the first build of this kernel 133 us for 433k x 32 rows, 7x its traffic).
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                              long V, int C, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
@@ -2673,50 +2712,60 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
                                                              float *__restrict__ dz, float *__restrict__ partial,
                                                              int rows_per_block)
 {
-    extern __shared__ float s_acc[];
-    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) s_acc[t] = 0.f;
-    __syncthreads();
-    const long e_begin = (long)blockIdx.x * rows_per_block * C;
-    const long e_end = min(V, (long)(blockIdx.x + 1) * rows_per_block) * C;
-    if ((C & 3) == 0 && (4 * 256) % C == 0) {
-        // 16 bytes per lane, and the four channels of a thread never change: sums in registers, eight LDS atomics per
-        // thread at the end (two per ELEMENT, ~240 cycles each, made this kernel 133 us for 433k x 32 rows: 7x its traffic)
-        const long v_begin = e_begin >> 2, v_end = e_end >> 2;
-        const int c = (int)((4 * (v_begin + threadIdx.x)) % C);
-        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
-        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
-        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    __shared__ float s_red[256 * 8];  // [thread][2][VEC]
+    const int CQ = C / VEC, rpp = 256 / CQ, tid = threadIdx.x;
+    const bool active = tid < rpp * CQ;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = min(V, r_begin + rows_per_block);
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; u++) s1[u] = s2[u] = 0.f;
+    if (active) {
+        const int c = (tid % CQ) * VEC;
+        const long stride = (long)rpp * CQ, e_end = r_end * CQ;
+        if (VEC == 4) {
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+            const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
 #pragma unroll 2
-        for (long v = v_begin + threadIdx.x; v < v_end; v += 256) {
-            const float4 xv = reinterpret_cast<const float4 *>(x)[v];
-            float4 g = reinterpret_cast<const float4 *>(dy)[v];
-            if (relu) {
-                if (!(fmaf(xv.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
-                if (!(fmaf(xv.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
-                if (!(fmaf(xv.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
-                if (!(fmaf(xv.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+            for (long e = r_begin * CQ + tid; e < e_end; e += stride) {
+                const float4 xv = reinterpret_cast<const float4 *>(x)[e];
+                float4 g = reinterpret_cast<const float4 *>(dy)[e];
+                if (relu) {
+                    if (!(fmaf(xv.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+                    if (!(fmaf(xv.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+                    if (!(fmaf(xv.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+                    if (!(fmaf(xv.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+                }
+                reinterpret_cast<float4 *>(dz)[e] = g;
+                s1[0] += g.x; s1[1 % VEC] += g.y; s1[2 % VEC] += g.z; s1[3 % VEC] += g.w;
+                s2[0] += g.x * ((xv.x - mu.x) * is.x); s2[1 % VEC] += g.y * ((xv.y - mu.y) * is.y);
+                s2[2 % VEC] += g.z * ((xv.z - mu.z) * is.z); s2[3 % VEC] += g.w * ((xv.w - mu.w) * is.w);
             }
-            reinterpret_cast<float4 *>(dz)[v] = g;
-            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-            s2.x += g.x * ((xv.x - mu.x) * is.x); s2.y += g.y * ((xv.y - mu.y) * is.y);
-            s2.z += g.z * ((xv.z - mu.z) * is.z); s2.w += g.w * ((xv.w - mu.w) * is.w);
-        }
-        atomicAdd(&s_acc[c + 0], s1.x); atomicAdd(&s_acc[c + 1], s1.y); atomicAdd(&s_acc[c + 2], s1.z); atomicAdd(&s_acc[c + 3], s1.w);
-        atomicAdd(&s_acc[C + c + 0], s2.x); atomicAdd(&s_acc[C + c + 1], s2.y);
-        atomicAdd(&s_acc[C + c + 2], s2.z); atomicAdd(&s_acc[C + c + 3], s2.w);
-    } else {
-        for (long e = e_begin + threadIdx.x; e < e_end; e += blockDim.x) {
-            const int c = (int)(e % C);
-            const float xv = x[e];
-            float g = dy[e];
-            if (relu && !(fmaf(xv, scale[c], shift[c]) > 0.f)) g = 0.f;
-            dz[e] = g;
-            atomicAdd(&s_acc[c], g);
-            atomicAdd(&s_acc[C + c], g * ((xv - mean[c]) * invstd[c]));
+        } else {
+            const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+#pragma unroll 2
+            for (long e = r_begin * CQ + tid; e < e_end; e += stride) {
+                const float xv = x[e];
+                float g = dy[e];
+                if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+                dz[e] = g;
+                s1[0] += g;
+                s2[0] += g * ((xv - mu) * is);
+            }
         }
     }
+#pragma unroll
+    for (int u = 0; u < VEC; u++) {
+        s_red[tid * 2 * VEC + u] = s1[u];
+        s_red[tid * 2 * VEC + VEC + u] = s2[u];
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + t] = s_acc[t];
+    for (int t = tid; t < 2 * C; t += 256) {
+        const int which = t >= C, c = t - which * C, cq = c / VEC, u = c - cq * VEC;
+        float sum = 0.f;
+        for (int j = 0; j < rpp; j++) sum += s_red[(j * CQ + cq) * 2 * VEC + which * VEC + u];
+        partial[(size_t)blockIdx.x * 2 * C + t] = sum;
+    }
 }
 
 // out[t] = sum_p partial[p][t]: 16 columns x 16 part-lanes per block, fixed combination order
@@ -2838,15 +2887,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_apply_kernel(const float *
 
 BnBwdState *bn_bwd_state(hipStream_t stream)
 {
+    // keyed by (device, stream): the null stream's handle is the same on every device
     static std::mutex lock;
-    static std::unordered_map<hipStream_t, BnBwdState *> states;
+    static std::map<std::pair<int, hipStream_t>, BnBwdState *> states;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> guard(lock);
-    auto it = states.find(stream);
+    auto it = states.find({dev, stream});
     if (it != states.end()) return it->second;
     BnBwdState *p = nullptr;
     if (hipMalloc((void **)&p, sizeof(BnBwdState)) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, sizeof(BnBwdState)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    states.emplace(stream, p);
+    states.emplace(std::make_pair(dev, stream), p);
     return p;
 }
 
@@ -3000,7 +3052,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         g.nblk = ntiles;
         g.G = K;
         g.rt = 1;
-        g.lds = ((size_t)(ks - 1) * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
+        g.lds = ((size_t)(ks - 1) * g.nbt * 256 + (with_bn_partial ? stat_slot_floats(g.nbt) : 0)) * sizeof(float) + 16;
         g.ok = ks <= 4 && g.nbt >= 1 && g.nbt <= MAX_NBT;
         // bf16x3 layers with three or more rounds of one-tile blocks: three tiles per block share every weight load
         // (spconv_fwd_small_bf3_rt_kernel) and one block per CU remains.  Measured at 11.7k rows, us per launch with 1 / 2 /
@@ -3015,7 +3067,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
                 g.rt = rt;
                 g.threads = waves * 64;
                 g.nblk = ms3d_divup(ntiles, rt);
-                g.lds = ((size_t)waves * rt * g.nbt * 256 + (with_bn_partial ? 2 * (size_t)Cout : 0)) * sizeof(float) + 16;
+                g.lds = ((size_t)waves * rt * g.nbt * 256 + (with_bn_partial ? waves * stat_slot_floats(g.nbt) : 0)) * sizeof(float) + 16;
             }
         }
         return g;
@@ -3098,7 +3150,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
     g.ny = ny;
     g.nbt = NBtot / ny;
     const size_t per_offset = (size_t)NCH * 4 * g.nbt * 64 * sizeof(float);  // LDS bytes per offset (column slice)
-    const size_t extra = with_bn_partial ? 2 * (size_t)Cout * sizeof(float) : 0;
+    const size_t extra = with_bn_partial ? STAT_MAX_WAVES * stat_slot_floats(g.nbt) * sizeof(float) : 0;  // a statistics slot per wave
     const bool resident = per_offset * K + extra <= LDS_BUDGET;
     if (resident) {
         g.G = K;
@@ -3197,6 +3249,8 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     if (aux_kind != 1 && aux_kind != 2) wf_stream = nullptr;
     p.pl_tile_start = pl_tile_start; p.pl_entries = pl_entries;
     p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
+    static const int dyn_picks = [] { const char *e = getenv("MS3D_PL_DYNAMIC"); return e ? atoi(e) : 0; }();
+    p.dyn_picks = dyn_picks;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
@@ -3268,7 +3322,7 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
         // three bf16 pieces are 6 bytes per weight
         const int nc32 = (Cin + 31) / 32;
         const size_t per_slab = (size_t)g.nbt * 3 * 1024;                 // one (offset, 32-channel chunk) of the slice
-        const size_t extra = (bn_x != nullptr || p.out_stats) ? 2 * (size_t)Cout * sizeof(float) : 0;
+        const size_t extra = (bn_x != nullptr || p.out_stats) ? STAT_MAX_WAVES * stat_slot_floats(g.nbt) * sizeof(float) : 0;
         const int slabs = (int)((LDS_BUDGET - extra) / per_slab);
         // a stage = one gather round's offsets x as many chunks as fit beside them.  (Layers whose f32 image is LDS
         // resident keep the f32 kernel: its grid is the persistent one.)
@@ -3561,8 +3615,8 @@ int ms3d_bn_stats(const float *x, long V, int C, float eps, float momentum, cons
     if (nblk > partial_rows) nblk = partial_rows;
     if (nblk < 1) nblk = 1;
     const int rows_per_block = (int)((V + nblk - 1) / nblk);
-    bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
-    MS3D_LAUNCH_CHECK();
+    const int rc = launch_bn_partial_stats(x, V, C, partial_ws, nblk, rows_per_block, stream);
+    if (rc) return rc;
     bn_finalize_stats_kernel<<<ms3d_divup(C, 16), 1024, 0, stream>>>(partial_ws, nblk, C, V, eps, momentum, gamma, beta,
                                                                   running_mean, running_var, mean, invstd, scale, shift);
     MS3D_LAUNCH_CHECK();
@@ -3583,8 +3637,8 @@ int ms3d_column_sum(const float *x, long V, int C, float *partial_ws, int partia
     if (nblk > partial_rows) nblk = partial_rows;
     if (nblk < 1) nblk = 1;
     const int rows_per_block = (int)((V + nblk - 1) / nblk);
-    bn_partial_stats_kernel<<<nblk, 256, 2 * C * sizeof(float), stream>>>(x, V, C, partial_ws, rows_per_block);
-    MS3D_LAUNCH_CHECK();
+    const int rc = launch_bn_partial_stats(x, V, C, partial_ws, nblk, rows_per_block, stream);
+    if (rc) return rc;
     return ms3d_reduce_partials(partial_ws, nblk, 2 * C, out2c, stream_);
 }
 
@@ -3675,9 +3729,14 @@ int ms3d_bn_bwd_partial(const float *dy, const float *x, long V, int C, const fl
     if (nblk > partial_rows) nblk = partial_rows;
     if (nblk < 1) nblk = 1;
     const int rows_per_block = (int)((V + nblk - 1) / nblk);
-    bn_bwd_partial_kernel<<<nblk, 256, 2 * C * sizeof(float), (hipStream_t)stream>>>(dy, x, V, C, scale, shift, mean,
-                                                                                    invstd, relu, dz, partial_ws,
-                                                                                    rows_per_block);
+    if ((C & 3) == 0 && C <= 1024)
+        bn_bwd_partial_kernel<4><<<nblk, 256, 0, (hipStream_t)stream>>>(dy, x, V, C, scale, shift, mean, invstd, relu, dz,
+                                                                        partial_ws, rows_per_block);
+    else if (C <= 256)
+        bn_bwd_partial_kernel<1><<<nblk, 256, 0, (hipStream_t)stream>>>(dy, x, V, C, scale, shift, mean, invstd, relu, dz,
+                                                                        partial_ws, rows_per_block);
+    else
+        return MS3D_E_UNSUPPORTED;
     MS3D_LAUNCH_CHECK();
     *nparts_out = nblk;
     return 0;

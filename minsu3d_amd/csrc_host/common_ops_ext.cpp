@@ -52,9 +52,14 @@ inline at::Tensor scratch(size_t bytes, const at::Tensor &like)
 // consumes that very graph skip a device->host check (-1 = unknown: decided on the device)
 struct LastGraph { const void *start_len = nullptr; int n = 0; int capped = -1; } g_last;
 
+// ONE use per ball query: the key is an address and a length, and the caching allocator may hand the same
+// address to a later start_len of equal length (or the caller may edit the tensor in place); the grouping that follows a
+// query consumes the hint, anything later decides on the device
 inline int capped_hint(const at::Tensor &start_len_dev)
 {
-    return (g_last.start_len == start_len_dev.data_ptr() && g_last.n == start_len_dev.size(0)) ? g_last.capped : -1;
+    const int hint = (g_last.start_len == start_len_dev.data_ptr() && g_last.n == start_len_dev.size(0)) ? g_last.capped : -1;
+    g_last = LastGraph();
+    return hint;
 }
 
 }  // namespace

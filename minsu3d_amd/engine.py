@@ -157,7 +157,8 @@ class Trainer:
                     # are built inside the grouping window (GeneralModel.schedule_after_backbone)
                     model.schedule_after_backbone(
                         lambda nb=upcoming: ME.prefetch_coordinates(nb["voxel_xyz"], model.backbone.n_levels,
-                                                                    channels=model.backbone.level_channels))
+                                                                    channels=model.backbone.level_channels,
+                                                                    point_map=nb.get("voxel_point_map")))
                 if self.ddp is model:
                     loss = model.training_step(batch)
                 else:                               # through the DDP wrapper: it arms the gradient all-reduce

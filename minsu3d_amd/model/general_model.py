@@ -151,11 +151,14 @@ def proposal_voxel_coords_torch(clusters_idx, clusters_offset, coords, scale, sp
     return torch.cat((clusters_idx[:, 0].int().unsqueeze(-1), vox), dim=1).contiguous()
 
 
-def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None):
+def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, device, rand=None,
+                          max_dup=None):
     """Per-proposal recentre / rescale into a `spatial_shape` cube, random placement, integer cast, dedupe into
     voxels (reference general_model.py:152-193).  `rand` = the two U(0,1)^3 draws shared by all proposals
-    (injected by parity tests).  -> (SparseTensor over proposal voxels, point->voxel map)"""
-    feats = ME.gather_rows(feats, clusters_idx[:, 1].long())
+    (injected by parity tests).  `max_dup`: the caller's bound on how many proposals one point can be a
+    member of (PointGroup: its two groupings -> 2; scheduling hint for the member gather's backward only).
+    -> (SparseTensor over proposal voxels, point->voxel map)"""
+    feats = ME.gather_rows(feats, clusters_idx[:, 1].long(), max_dup)
     if rand is not None:
         u = torch.cat((rand[0].reshape(3), rand[1].reshape(3))).to(device=coords.device, dtype=torch.float32)
     else:

@@ -53,7 +53,8 @@ class HAIS(GeneralModel):
             out["proposal_scores"] = (z, proposals_idx, proposals_offset, z)
             return out
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"], data_dict["point_xyz"],
-                                         net.score_scale, net.score_fullscale, self.device, rand=self.voxelization_rand)
+                                         net.score_scale, net.score_fullscale, self.device, rand=self.voxelization_rand,
+                                         max_dup=1)                 # a point belongs to at most one aggregated cluster
         inst = self.tiny_unet(vox)
         score_feats = inst.features[p2v]
         mask_scores = self.mask_branch(inst.features)[p2v]        # linear on voxels first, then voxel -> point

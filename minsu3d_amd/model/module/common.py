@@ -73,6 +73,10 @@ class ResidualBlock(nn.Module):
         bn0, _, conv1, bn1, _, conv2 = plan[:6]
         if not conv1.kernel.is_cuda:
             return None
+        if not (bn0.training and bn1.training and conv2.training):
+            # a BatchNorm frozen with .eval() inside a train()-mode block normalises with its running statistics (and a
+            # convolution in eval mode collects none for the next one): the module chain honours that
+            return None
         cm, ts = x.coordinate_manager, x.tensor_stride
         nbr, V = cm.k3(ts), cm.size(ts)
         spec = ME_F.ConvSpec(nbr, nbr, V, V, 27, conv1.in_channels, conv1.out_channels, True)
@@ -144,6 +148,8 @@ def _bn_relu_conv_fused(seq, x):
     bn, _, conv = plan
     st = x._stats
     if isinstance(st, tuple) and sum(p.size(2) for p in st) != x._F.size(1):
+        return seq(x)
+    if not (bn.training and conv.training):     # a frozen BatchNorm inside a train()-mode network: the module chain
         return seq(x)
     cm, ts = x.coordinate_manager, x.tensor_stride
     if isinstance(conv, ME.MinkowskiConvolutionTranspose):

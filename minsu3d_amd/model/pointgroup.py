@@ -96,7 +96,7 @@ class PointGroup(GeneralModel):
             return out
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"],
                                          data_dict["point_xyz"], net.score_scale, net.score_fullscale, self.device,
-                                         rand=self.voxelization_rand)
+                                         rand=self.voxelization_rand, max_dup=2)   # a point: <= one cluster per grouping
         score_feats = ME.gather_rows(self.score_net(vox).features, p2v)      # (sumNPoint, m)
         pooled = common_ops.roipool(score_feats, proposals_offset)            # (nProposal, m)
         out["proposal_scores"] = (self.score_branch(pooled), proposals_idx, proposals_offset)

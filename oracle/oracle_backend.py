@@ -68,7 +68,7 @@ class OracleBackend:
 
     def roipool_bp(self, d_out, off, maxidx, n): return _t(O.roipool_bp(_np(d_out), _np(off), _np(maxidx), n))
     def global_avg_pool_bp(self, d_out, off, n): return _t(O.global_avg_pool_bp(_np(d_out), _np(off), n))
-    def scatter_add_rows(self, src, idx, n_rows):
+    def scatter_add_rows(self, src, idx, n_rows, max_dup=None):   # max_dup: a scheduling hint of the device backend
         dst = torch.zeros((n_rows, src.size(1)), dtype=torch.float32)
         return dst.index_add_(0, idx, src)
 

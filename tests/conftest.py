@@ -22,3 +22,19 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# Collection order (VERDICT r4 #1b): kernel-level parity first, then the operator boundaries, the whole-model pins, the
+# training machinery, and the multi-process data-parallel test last -- so that `-x` stops as late as possible and a
+# failure in the machinery cannot hide the kernel suites behind it.  Files not listed keep their alphabetical place.
+_ORDER = ["test_oracle_grouping", "test_abi_cpu", "test_grouping_gpu", "test_sparse_cpu", "test_sparse_gpu",
+          "test_fullsize_gpu", "test_dropin_cpu", "test_dropin_gpu", "test_reference_pins_cpu", "test_reference_pins_gpu",
+          "test_forward_pins_cpu", "test_forward_pins_gpu", "test_postprocess_cpu", "test_postprocess_gpu",
+          "test_transform_cpu", "test_dataset_cpu", "test_dataset_gpu", "test_dataset_pins_cpu", "test_dataset_pins_gpu",
+          "test_evaluation_cpu", "test_determinism_gpu", "test_model_cpu", "test_model_gpu", "test_engine_cpu",
+          "test_engine_gpu", "test_convergence_gpu", "test_bench_cpu", "test_ddp_gpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.splitext(os.path.basename(str(it.fspath)))[0], len(_ORDER) // 2))

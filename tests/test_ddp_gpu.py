@@ -1,0 +1,130 @@
+"""GPU: the data-parallel training path (reference config/model/base.yaml:13-16: Lightning DDP, one process per GPU) on
+the one device of the test box -- two ranks over gloo sharing it (RCCL refuses two ranks on one device).
+
+Round 4's single test compared the all-reduced gradients of a TRAINING-mode step with a second evaluation of the same
+step whose BatchNorm statistics differed in the last bits (LDS float atomics), and failed on the driver's box at 2.7e-3
+when a ReLU mask flipped between the two evaluations.  Round 5 made the step bit-reproducible
+(tests/test_determinism_gpu.py), so the check is now exact arithmetic and split in two:
+
+  * completeness -- what DistributedDataParallel's bucket hooks all-reduced is the average of the ranks' COMPLETE local
+    gradients, per parameter tensor, for every combination of the machinery that sits between a backward-weight kernel
+    and the hook: fused block nodes on / off, deferred + batched slab reductions on / off, backward-weight on a second
+    stream (MS3D_WGRAD_STREAM=1).  A hook that fired before its layer group's flush would average unreduced slabs --
+    identically on both ranks, so only the comparison with the plain module chain notices;
+  * stay in step -- three training steps with the one-launch Adam: bit-identical, finite parameters on both ranks."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (fused block nodes, deferred slab reductions, backward-weight stream mode)
+CONFIGS = [(True, True, 0), (False, True, 0), (True, False, 0), (False, False, 0), (True, True, 1)]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MS3D_SHARE_DEVICE="1", MS3D_DIST_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    from minsu3d_amd import backend as ms_backend
+    from minsu3d_amd.model.module import common
+    from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp
+    from test_model_cpu import build_model as bm, small_batch as sb
+    init_distributed()
+    dev = torch.device("cuda", 0)
+    be = ms_backend.get_backend()
+    u = (torch.tensor([0.3, 0.6, 0.9], device=dev), torch.tensor([0.1, 0.2, 0.3], device=dev))
+
+    def set_config(fuse, defer, stream_mode):
+        common._FUSE_BLOCKS = fuse
+        be._wgrad_mode = stream_mode
+        be._wgrad_defer = bool(defer and stream_mode == 0)
+
+    def local_grads(model, batch):
+        model.zero_grad(set_to_none=True)
+        sum(model._loss(batch, model(batch)).values()).backward()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    seeds = shard_scene_seeds(step=0, scenes_per_rank=2, rank=rank, world_size=world)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb(tuple(seeds)).items()}
+    # the reference: the plain module chain, per-layer slab reductions, one stream, no wrapper; averaged by hand
+    model = bm(seed=0).to(dev)
+    model.train()
+    model.voxelization_rand = u
+    set_config(False, False, 0)
+    want = []
+    for g in local_grads(model, batch):
+        parts = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        want.append(torch.stack(parts).mean(0))
+    names = [n for n, _ in model.named_parameters()]
+    ddp = wrap_ddp(model, dev, find_unused_parameters=False)
+    errs = {}
+    for cfg in CONFIGS:
+        set_config(*cfg)
+        if cfg[1] and cfg[2] == 0:
+            assert be.wgrad_queue() is not None                       # the deferral is what runs below
+        model.zero_grad(set_to_none=True)
+        sum(model._loss(batch, ddp(batch)).values()).backward()
+        torch.cuda.synchronize()
+        worst = (0.0, "")
+        for n, p, w in zip(names, model.parameters(), want):
+            e = float((p.grad - w).abs().max() / (w.abs().max() + 1e-12))
+            if e > worst[0]:
+                worst = (e, n)
+        errs[str(cfg)] = worst
+    # stay in step: three optimizer steps on disjoint scenes with the default machinery
+    set_config(True, True, 0)
+    opt = model.configure_optimizers()
+    losses = []
+    for step in range(3):
+        seeds = shard_scene_seeds(step=step, scenes_per_rank=2, rank=rank, world_size=world)
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb(tuple(seeds)).items()}
+        opt.zero_grad(set_to_none=True)
+        loss = sum(model._loss(b, ddp(b)).values())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, type(opt).__module__, losses, all(torch.equal(gathered[0], t) for t in gathered),
+           bool(torch.isfinite(flat).all()), errs))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "fused%d-defer%d-stream%d" % (int(c[0]), int(c[1]), c[2]))
+def test_ddp_all_reduces_complete_gradients(two_ranks, cfg):
+    """per parameter tensor: |all-reduced - average of the ranks' local gradients| <= 1e-5 of the tensor's largest entry
+    (the step is bit-reproducible and the configurations run the same kernels in the same order, so the expected
+    difference is the rounding of gloo's sum against torch's mean: measured 0 .. 1e-7)"""
+    for r in two_ranks:
+        err, name = r[5][str(cfg)]
+        assert err <= 1e-5, (cfg, name, err)
+
+
+def test_ddp_two_ranks_on_one_gpu_stay_in_step(two_ranks):
+    res = two_ranks
+    assert res[0][1] == res[1][1] == "minsu3d_amd.optim"      # the library's Adam is what stepped
+    assert res[0][2] != res[1][2]                             # different scenes, different losses
+    assert res[0][3] and res[1][3] and res[0][4]              # identical, finite parameters on both ranks

@@ -661,3 +661,64 @@ def test_fused_bn_backward_chain_is_bit_identical(be, V, C_, nparts, with_add):
     _lib.check(lib.ms3d_bn_bwd_reduce_apply(p(partial), nparts, None, None, C.c_long(V), C_, None, None, None, None, None,
                                             p(sums_only), st), "fused sums")
     assert torch.equal(sums_only, want_s)
+
+
+@pytest.mark.parametrize("fused_chain", [False, True])
+def test_shared_convolution_called_twice_keeps_its_own_slab_reduction(be, fused_chain):
+    """inside a prepare_conv_weights window a convolution hands autograd a dW that only the group's
+    flush node fills.  ONE module called TWICE in a forward (weight sharing) would make autograd add the two still-unwritten
+    tensors before the flush -- such a kernel must fall back to reducing its own slabs.  Gradients with the deferral on
+    equal the gradients with MS3D_WGRAD_DEFER=0, bit for bit, while an ordinary second convolution of the same group keeps
+    its deferral (the queue is used)."""
+    from minsu3d_amd import MinkowskiEngine as ME
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import WgradQueue
+    backend.set_backend(be)
+    rng = np.random.default_rng(7)
+    coords = dev(surface_coords(rng, 2, 24000))
+    feats = torch.randn(coords.size(0), 16, generator=torch.Generator().manual_seed(1)).cuda()
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shared = ME.MinkowskiConvolution(16, 16, kernel_size=3, dimension=3)
+            self.bn = ME.MinkowskiBatchNorm(16)
+            self.relu = ME.MinkowskiReLU()
+            self.other = ME.MinkowskiConvolution(16, 16, kernel_size=3, dimension=3)
+
+        def forward(self, x):
+            y = self.shared(x)
+            if fused_chain:
+                y = self.relu(self.bn(y))
+            y = self.shared(y)                      # the same kernel a second time
+            return self.other(self.relu(self.bn(y)))
+
+    net = Net().cuda().train()
+    g = torch.randn(coords.size(0), 16, generator=torch.Generator().manual_seed(2)).cuda()
+    seen = []
+    real_add = WgradQueue.add
+
+    def grads(defer):
+        be._wgrad_defer = defer
+        net.zero_grad(set_to_none=True)
+        ME.prepare_conv_weights(net)
+        try:
+            out = net(ME.SparseTensor(features=feats, coordinates=coords))
+        finally:
+            ME.release_conv_weights()
+        (out.F * g).sum().backward()
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+    WgradQueue.add = lambda self, *a: (seen.append(a[2]), real_add(self, *a))[1]
+    try:
+        want = grads(False)
+        assert not seen
+        got = grads(True)
+    finally:
+        WgradQueue.add = real_add
+        be._wgrad_defer = None
+    assert len(seen) == 1                            # `other` deferred its reduction, the shared kernel did not
+    for n in want:
+        assert torch.equal(got[n], want[n]), n
+    assert float(want["shared.kernel"].abs().max()) > 0
