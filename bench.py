@@ -235,6 +235,10 @@ def roofline_report(groups, n_sampled, lib, model_name="pointgroup"):
         if t.get("kernel_source_digest") == kernel_source_digest():
             roof["traffic"] = t.get("spconv_hbm_bytes_per_step")
             roof["traffic_source"] = f"profiles/{os.path.basename(tfile)} ({t.get('commit', '?')}): {t.get('method', '')}"
+            if roof["traffic"]:
+                # `frac` is an ALGORITHMIC rate (a voxel row fetched from HBM once is re-gathered from L2 for its other
+                # pairs); this one is the physical HBM rate of the same kernels: counter bytes / kernel time / peak
+                roof["hbm_frac_physical"] = round(roof["traffic"] / (tot["ms"] / n_sampled * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         else:   # counters of other code are not this code's traffic
             roof["traffic_source"] = (f"profiles/{os.path.basename(tfile)} was measured on other kernel sources "
                                       f"(digest {t.get('kernel_source_digest')} != {kernel_source_digest()}): not reported")
@@ -387,7 +391,11 @@ def main(argv=None):
         scenes = world * args.batch * args.steps
         line = {
             "metric": f"scenes/sec (fwd+bwd) {cfg.model.network.module} on ~150k-pt 2cm voxels",
-            "value": round(scenes / dt, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
+            "value": round(scenes / dt, 3), "unit": "scenes/sec",
+            # the same rate from the MEDIAN step (rank 0's clock): `value` is wall time over all steps incl. the first
+            # step's empty pipeline and any host hiccup of the box; the two together show the box noise in one line
+            "value_median": round(world * args.batch / (float(np.median(step_ms)) * 1e-3), 3),
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "step_ms": {"median": round(float(np.median(step_ms)), 3), "min": round(float(step_ms.min()), 3),
                         "max": round(float(step_ms.max()), 3), "mean": round(float(step_ms.mean()), 3),

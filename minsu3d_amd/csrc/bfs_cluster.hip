@@ -163,18 +163,49 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
 {
     const int waves = blockDim.x >> 6;
     const int l = lane_id();
-    for (int i = blockIdx.x * waves + wave_id(); i < N; i += gridDim.x * waves) {
-        const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
-        if (ln <= 1) continue;  // only itself
-        const int lab = thr.mode == 0 ? (int)sem[i] : 0;
-        int ri = parent[i];     // compressed: the root as of the last compress pass (a stale value only costs a find)
-        // four 64-edge slices per trip: the index loads, then the parent gathers are in flight together
-        for (int t0 = 0; t0 < ln; t0 += 256) {
-            int j[4], pj[4];
+    // A point is a chain of dependent round trips (list header / own root -> list slices -> the neighbours' roots): the
+    // header of the point after next and the first slices of the next point are requested while this point's gathers are
+    // in flight (round 5: 250-315 us -> see profiles/r05_*; a stale own root only costs a find).
+    const int stride = gridDim.x * waves;
+    struct Hdr { int st, ln, lab, ri; };
+    auto load_hdr = [&](int i) {
+        Hdr h{0, 0, 0, 0};
+        if (i < N) {
+            h.st = start_len[i * 2]; h.ln = start_len[i * 2 + 1];
+            h.lab = thr.mode == 0 ? (int)sem[i] : 0;
+            h.ri = parent[i];
+        }
+        return h;
+    };
+    auto load_slices = [&](const Hdr &h, int (&j)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = t0 + 64 * u + l;
-                j[u] = t < ln ? ball_idx[st + t] : INT_BIG;
+        for (int u = 0; u < 4; u++) {
+            const int t = 64 * u + l;
+            j[u] = t < h.ln ? ball_idx[h.st + t] : INT_BIG;
+        }
+    };
+    int i = blockIdx.x * waves + wave_id();
+    Hdr hA = load_hdr(i), hB = load_hdr(i + stride);
+    int jA[4];
+    load_slices(hA, jA);
+    for (; i < N; i += stride) {
+        const Hdr hC = load_hdr(i + 2 * stride);
+        int jB[4];
+        load_slices(hB, jB);
+        const int st = hA.st, ln = hA.ln, lab = hA.lab;
+        int ri = hA.ri;         // compressed: the root as of the last compress pass
+        // four 64-edge slices per trip: the index loads, then the parent gathers are in flight together
+        for (int t0 = 0; t0 < ln && ln > 1; t0 += 256) {
+            int j[4], pj[4];
+            if (t0 == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) j[u] = jA[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u + l;
+                    j[u] = t < ln ? ball_idx[st + t] : INT_BIG;
+                }
             }
             // lists are ascending: once a slice starts at or above i the rest of a symmetric graph's list is the other
             // end's business
@@ -204,6 +235,9 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
                 ri = rnew;
             }
         }
+        hA = hB; hB = hC;
+#pragma unroll
+        for (int u = 0; u < 4; u++) jA[u] = jB[u];
     }
 }
 
@@ -829,6 +863,384 @@ __global__ __launch_bounds__(256) void glob_win_kernel(int level, const int *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same three passes with LDS-resident node BITMAPS (round 5).  The passes above look every edge's target up with an
+// 8-byte gather of its node word: ~3 x 120 M gathers per PointGroup graph against ~240 G cached gathers / s on this part
+// (tools/gather_micro.hip) -- that, not the 480 MB edge list, is what a level costs.  But each pass asks ONE yes / no
+// question per edge before it needs anything else:
+//   mark : is j unvisited?                       -> bitmap V  (bit j = node j has a level)
+//   pull : is j in the frontier of level L?      -> bitmap F  (bit j = level(j) == L), then the node word of those only
+//   win  : was j claimed for level L + 1?        -> bitmap C  (set by pull), then the claim word of those only
+// N bits are 50 KB for the 400 k foreground points of a 4-scene batch: every workgroup copies the level's bitmap into LDS
+// (1024 threads, two workgroups per CU: 25 MB of L2 reads per pass) and an edge costs one ds_read instead of one L2
+// gather; the 8-byte gathers that remain are the frontier members (pull) and the claimed children (win).
+// `mark` no longer tests the label of j (it has only the bit): a neighbour of another label becomes a candidate, scans
+// its own list in `pull` for level-L nodes of ITS label, and either finds none (nothing happens) or finds its true
+// parent -- it was a legitimate candidate of its own component then, whose frontier marks it as well.  Same clusters,
+// same order (tests: golden / KAT / full-scene cases run through these kernels by default; MS3D_BFS_BITMAP=0 = the
+// passes above).  glob_bits_kernel builds V and F from the node words and clears C once per level.
+constexpr int BM_THREADS = 1024;
+
+__global__ void glob_bits_kernel(int N, int level, const unsigned long long *__restrict__ vp, unsigned long long *Vb,
+                                 unsigned long long *Fb, unsigned long long *Cb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lvl = i < N ? (unsigned)(vp[i] >> 48) : 0xFFFFu;
+    const unsigned long long mv = __ballot(lvl != 0xFFFFu), mf = __ballot(i < N && lvl == (unsigned)(level & 0xFFFF));
+    if (lane_id() == 0 && (i >> 6) <= ((N - 1) >> 6)) {
+        Vb[i >> 6] = mv;
+        Fb[i >> 6] = mf;
+        Cb[i >> 6] = 0ull;
+    }
+}
+
+__device__ __forceinline__ void bm_load(unsigned *s_bits, const unsigned long long *__restrict__ bm, int nwords64)
+{
+    // 16 bytes per lane; the bitmap arrays are 16-byte aligned and padded to an even number of 64-bit words
+    const uint4 *src = reinterpret_cast<const uint4 *>(bm);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_bits);
+    for (int w = threadIdx.x; w < (nwords64 + 1) / 2; w += blockDim.x) dst[w] = src[w];
+}
+__device__ __forceinline__ bool bm_test(const unsigned *s_bits, int j) { return (s_bits[j >> 5] >> (j & 31)) & 1u; }
+
+__global__ __launch_bounds__(BM_THREADS) void glob_mark_bm_kernel(
+    int level, const int *__restrict__ ball_idx, const int *__restrict__ start_len, const int *__restrict__ root,
+    const int *__restrict__ F, int *counters, const int *__restrict__ worklist, const int *__restrict__ comp_base,
+    const int *__restrict__ done_cur, int *done_next, const int *__restrict__ seg_start_cur, int *seg_start_next,
+    const int *__restrict__ seg_cnt_cur, int *seg_cnt_next, int *cand, int *cnt, int *scratch_node, int *scratch_seed,
+    unsigned long long *tile_status, const unsigned long long *__restrict__ Vb, int nwords64)
+{
+    extern __shared__ unsigned s_bits[];
+    const int nF = counters[6 + (level & 1)];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    {
+        const int nwork = counters[0];
+        for (int w = gid; w < nwork; w += gsz) {
+            const int r = worklist[w];
+            done_next[r] = done_cur[r] + seg_cnt_cur[r];
+            seg_start_next[r] = INT_BIG;
+            seg_cnt_next[r] = 0;
+        }
+        const int ntiles = (nF + WIN_TILE - 1) / WIN_TILE;
+        for (int t = gid; t < ntiles; t += gsz) tile_status[t] = 0ull;
+        if (gid == 0) {
+            counters[8] = 0;
+            counters[6 + ((level + 1) & 1)] = 0;
+            if (nF > 0) counters[14] = level + 1;
+        }
+    }
+    const int waves = blockDim.x >> 6, l = lane_id();
+    if (blockIdx.x * waves >= nF) return;            // an exhausted level (or a surplus workgroup): no bitmap copy
+    bm_load(s_bits, Vb, nwords64);
+    __syncthreads();
+    // A frontier node is a chain of dependent round trips -- F[p] -> list header / root -> list slices / component
+    // bookkeeping -- in front of a few LDS bit tests: the wave's nodes go through a three-stage software pipeline
+    // (node A's edges are tested while node B's slices, node C's header and node D's id are in flight).
+    const int stride = gridDim.x * waves;
+    struct Hdr { int node, st, ln, r; };
+    struct Body { int j[4], base, done, seg; };
+    auto load_id = [&](int p) { return p < nF ? F[p] : -1; };
+    auto load_hdr = [&](int node) {
+        Hdr h{node, 0, 0, 0};
+        if (node >= 0) { h.st = start_len[node * 2]; h.ln = start_len[node * 2 + 1]; h.r = root[node]; }
+        return h;
+    };
+    auto load_body = [&](const Hdr &h) {
+        Body b;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = 64 * u + l;
+            b.j[u] = (h.node >= 0 && t < h.ln) ? ball_idx[h.st + t] : -1;
+        }
+        b.base = b.done = b.seg = 0;
+        if (h.node >= 0) { b.base = comp_base[h.r]; b.done = done_cur[h.r]; b.seg = seg_start_cur[h.r]; }
+        return b;
+    };
+    int p = blockIdx.x * waves + wave_id();
+    Hdr hA = load_hdr(load_id(p)), hB = load_hdr(load_id(p + stride));
+    int idC = load_id(p + 2 * stride);
+    Body bA = load_body(hA);
+    for (; p < nF; p += stride) {
+        const int idD = load_id(p + 3 * stride);
+        const Hdr hC = load_hdr(idC);
+        const Body bB = load_body(hB);
+        // ---- node A
+        if (l == 0) {
+            const int qpos = bA.base + bA.done + (p - bA.seg);
+            scratch_node[qpos] = hA.node;
+            scratch_seed[qpos] = hA.r;
+            cnt[p] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (bA.j[u] >= 0 && !bm_test(s_bits, bA.j[u])) cand[bA.j[u]] = level + 1;
+        for (int t0 = 256; t0 < hA.ln; t0 += 256) {          // lists beyond 256 entries: the rest, slice group by slice group
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u + l;
+                j[u] = t < hA.ln ? ball_idx[hA.st + t] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (j[u] >= 0 && !bm_test(s_bits, j[u])) cand[j[u]] = level + 1;
+        }
+        hA = hB; bA = bB; hB = hC; idC = idD;
+    }
+}
+
+// a workgroup per 1024 nodes: the candidates among them are compacted in LDS, then its 16 waves take them in turn
+__global__ __launch_bounds__(BM_THREADS) void glob_pull_bm_kernel(int N, int level, const int *__restrict__ ball_idx,
+                                                                  const int *__restrict__ start_len,
+                                                                  const unsigned long long *__restrict__ vp,
+                                                                  const int *__restrict__ cand,
+                                                                  unsigned long long *__restrict__ cc, int *cnt,
+                                                                  const int *__restrict__ counters,
+                                                                  const unsigned long long *__restrict__ Fb, unsigned *Cb32,
+                                                                  int nwords64)
+{
+    extern __shared__ unsigned s_bits[];
+    __shared__ int s_list[BM_THREADS];
+    __shared__ int s_n;
+    if (counters[6 + (level & 1)] == 0) return;      // exhausted level
+    bm_load(s_bits, Fb, nwords64);
+    const int l = lane_id(), waves = blockDim.x >> 6;
+    for (int base_node = blockIdx.x * BM_THREADS; base_node < N; base_node += gridDim.x * BM_THREADS) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const int i = base_node + threadIdx.x;
+        const bool is_cand = i < N && cand[i] == level + 1;
+        const unsigned long long m = __ballot(is_cand);
+        int base = 0;
+        if (l == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (is_cand) s_list[base + ballot_rank(m)] = i;
+        __syncthreads();
+        const int n = s_n;
+        // two-stage pipeline over the wave's candidates: node B's header / own word, then its first slices, are requested
+        // while node A's slices are tested (the candidate ids come from LDS)
+        struct Hdr { int node, st, ln; unsigned long long w; };
+        auto load_hdr = [&](int k) {
+            Hdr h{-1, 0, 0, 0ull};
+            if (k < n) { h.node = s_list[k]; h.st = start_len[h.node * 2]; h.ln = start_len[h.node * 2 + 1]; h.w = vp[h.node]; }
+            return h;
+        };
+        auto load_slices = [&](const Hdr &h, int (&j)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = 64 * u + l;
+                j[u] = (h.node >= 0 && t < h.ln) ? ball_idx[h.st + t] : -1;
+            }
+        };
+        int k = wave_id();
+        Hdr hA = load_hdr(k), hB = load_hdr(k + waves);
+        int jA[4];
+        load_slices(hA, jA);
+        for (; k < n; k += waves) {
+            const Hdr hC = load_hdr(k + 2 * waves);
+            int jB[4];
+            load_slices(hB, jB);
+            const unsigned long long want = vp_make(level, (int)((hA.w >> 32) & 0xFFFF), 0) >> 32;  // level L, my label
+            unsigned best = 0xFFFFFFFFu;
+            {
+                unsigned long long v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (jA[u] >= 0 && bm_test(s_bits, jA[u])) ? vp[jA[u]] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((v[u] >> 32) == want) best = min(best, (unsigned)v[u]);
+            }
+            for (int t0 = 256; t0 < hA.ln; t0 += 256) {
+                int j[4];
+                unsigned long long v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u + l;
+                    j[u] = t < hA.ln ? ball_idx[hA.st + t] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (j[u] >= 0 && bm_test(s_bits, j[u])) ? vp[j[u]] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((v[u] >> 32) == want) best = min(best, (unsigned)v[u]);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, d, 64));
+            if (l == 0 && best != 0xFFFFFFFFu) {
+                cc[hA.node] = ((unsigned long long)(unsigned)(level + 1) << 32) | best;
+                atomicAdd(&cnt[best], 1);
+                atomicOr(&Cb32[hA.node >> 5], 1u << (hA.node & 31));
+            }
+            hA = hB; hB = hC;
+#pragma unroll
+            for (int u = 0; u < 4; u++) jA[u] = jB[u];
+        }
+        __syncthreads();
+    }
+}
+
+// win with bitmaps: a workgroup takes tiles of WIN_BM_TILE frontier positions off the ticket counter, compacts the
+// positions that have children, with their output offsets, into an LDS list, and its waves walk that list through the
+// same three-stage pipeline as `mark` (id -> list header -> list slices in flight for three entries at once).
+// (tile size: a level's frontier is 10^4..10^5 positions and every tile is one workgroup's work item -- 1024-position
+// tiles left 200 of 256 CUs without one; 128 positions x 512 threads, two workgroups per CU, measured best)
+constexpr int WIN_BM_THREADS = 512;
+constexpr int WIN_BM_TILE = 128;
+static_assert(WIN_BM_TILE % WIN_TILE == 0, "tile_status is cleared per WIN_TILE positions: a coarser tile uses a prefix of it");
+
+__global__ __launch_bounds__(WIN_BM_THREADS) void glob_win_bm_kernel(int level, const int *__restrict__ ball_idx,
+                                                                 const int *__restrict__ start_len,
+                                                                 const int *__restrict__ root, const int *__restrict__ F,
+                                                                 int *counters, const int *__restrict__ cnt,
+                                                                 const unsigned long long *__restrict__ cc,
+                                                                 unsigned long long *vp, unsigned long long *tile_status,
+                                                                 int *F_next, int *seg_start_next, int *seg_cnt_next,
+                                                                 const unsigned long long *__restrict__ Cb, int nwords64)
+{
+    extern __shared__ unsigned s_bits[];
+    __shared__ int s_wtot[WIN_BM_THREADS / 64];
+    __shared__ int s_wbase[WIN_BM_THREADS / 64];
+    __shared__ int s_lpos[WIN_BM_TILE];    // live entries: position in the tile | children << 16 ... kept as two arrays
+    __shared__ int s_lout[WIN_BM_TILE];
+    __shared__ int s_lcnt[WIN_BM_TILE];
+    __shared__ int s_bcast[3];
+    const int nF = counters[6 + (level & 1)];
+    const int ntiles = (nF + WIN_BM_TILE - 1) / WIN_BM_TILE;
+    const int l = lane_id(), wv = wave_id(), waves = blockDim.x >> 6;
+    constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INCL = 2ull << 62, VAL = (1ull << 62) - 1;
+    if ((int)blockIdx.x >= ntiles) return;  // surplus workgroups leave without touching the ticket counter
+    bm_load(s_bits, Cb, nwords64);
+    for (;;) {
+        if (threadIdx.x == 0) { s_bcast[0] = atomicAdd(&counters[8], 1); s_bcast[2] = 0; }
+        __syncthreads();
+        const int tile = s_bcast[0];
+        if (tile >= ntiles) break;
+        const int pos = tile * WIN_BM_TILE + threadIdx.x;
+        const int v = ((int)threadIdx.x < WIN_BM_TILE && pos < nF) ? cnt[pos] : 0;
+        const int incl = wave_incl_scan(v);
+        if (l == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        if (wv == 0) {
+            const int wt = l < waves ? s_wtot[l] : 0;
+            const int wincl = wave_incl_scan(wt);
+            if (l < waves) s_wbase[l] = wincl - wt;
+            const int total = __shfl(wincl, 63, 64);
+            // relaxed on purpose (see glob_win_kernel): the word carries its own payload
+            if (l == 0)
+                __hip_atomic_store(&tile_status[tile], (tile == 0 ? FLAG_INCL : FLAG_AGG) | (unsigned long long)total,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int base = 0;
+            for (int hi = tile - 1; hi >= 0;) {
+                const int t = hi - l;
+                const unsigned long long sv = t >= 0 ? __hip_atomic_load(&tile_status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                     : FLAG_INCL;
+                const unsigned long long incl_m = __ballot((sv >> 62) == 2ull), inval_m = __ballot((sv >> 62) == 0ull);
+                const int first = incl_m ? __ffsll((long long)incl_m) - 1 : 64;
+                const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                if (inval_m & need) {
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                base += wave_sum(l <= first ? (int)(sv & VAL) : 0);
+                if (first < 64) break;
+                hi -= 64;
+            }
+            if (l == 0) {
+                if (tile > 0)
+                    __hip_atomic_store(&tile_status[tile], FLAG_INCL | (unsigned long long)(base + total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_bcast[1] = base;
+                if (tile == ntiles - 1) counters[6 + ((level + 1) & 1)] = base + total;
+            }
+        }
+        __syncthreads();
+        {
+            // the positions with children -> the live list (any order: an entry carries its own output offset)
+            const int out = s_bcast[1] + s_wbase[wv] + incl - v;
+            const unsigned long long live = __ballot(v > 0);
+            int lb = 0;
+            if (l == 0 && live) lb = atomicAdd(&s_bcast[2], __popcll(live));
+            lb = __shfl(lb, 0, 64);
+            if (v > 0) {
+                const int e = lb + ballot_rank(live);
+                s_lpos[e] = pos;
+                s_lout[e] = out;
+                s_lcnt[e] = v;
+            }
+        }
+        __syncthreads();
+        const int nlive = s_bcast[2];
+        // ---- children out, in (position, slot) order; entries of a wave pipelined: A walked, B's slices, C's header, D's id in flight
+        struct Hdr { int pos, out, n, node, st, ln, r; unsigned long long w; };
+        auto load_id = [&](int k) {
+            Hdr h{0, 0, 0, -1, 0, 0, 0, 0ull};
+            if (k < nlive) { h.pos = s_lpos[k]; h.out = s_lout[k]; h.n = s_lcnt[k]; h.node = F[h.pos]; }
+            return h;
+        };
+        auto load_hdr = [&](Hdr &h) {
+            if (h.node >= 0) {
+                h.st = start_len[h.node * 2]; h.ln = start_len[h.node * 2 + 1]; h.r = root[h.node]; h.w = vp[h.node];
+            }
+        };
+        auto load_slices = [&](const Hdr &h, int (&j)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = 64 * u + l;
+                j[u] = (h.node >= 0 && t < h.ln) ? ball_idx[h.st + t] : -1;
+            }
+        };
+        int k = wv;
+        Hdr hA = load_id(k), hB = load_id(k + waves), hC = load_id(k + 2 * waves);
+        load_hdr(hA); load_hdr(hB);
+        int jA[4];
+        load_slices(hA, jA);
+        for (; k < nlive; k += waves) {
+            Hdr hD = load_id(k + 3 * waves);
+            load_hdr(hC);
+            int jB[4];
+            load_slices(hB, jB);
+            int out = hA.out;
+            if (l == 0) {
+                atomicMin(&seg_start_next[hA.r], out);
+                atomicAdd(&seg_cnt_next[hA.r], hA.n);
+            }
+            const unsigned long long mine = ((unsigned long long)(unsigned)(level + 1) << 32) | (unsigned)hA.pos;
+            const unsigned long long lab = hA.w & (0xFFFFull << 32);
+            for (int t0 = 0; t0 < hA.ln; t0 += 256) {
+                int j[4];
+                unsigned long long c[4];
+                if (t0 == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) j[u] = jA[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int t = t0 + 64 * u + l;
+                        j[u] = t < hA.ln ? ball_idx[hA.st + t] : -1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) c[u] = (j[u] >= 0 && bm_test(s_bits, j[u])) ? cc[j[u]] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool win = c[u] == mine;
+                    const unsigned long long wm = __ballot(win);
+                    if (win) {
+                        const int o = out + ballot_rank(wm);
+                        F_next[o] = j[u];
+                        vp[j[u]] = ((unsigned long long)(unsigned)((level + 1) & 0xFFFF) << 48) | lab | (unsigned)o;
+                    }
+                    out += __popcll(wm);
+                }
+            }
+            hA = hB; hB = hC; hC = hD;
+#pragma unroll
+            for (int u = 0; u < 4; u++) jA[u] = jB[u];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // DIRECTED dense graphs (some list was cut at the 1000-neighbour cap, e.g. SoftGroup's r = 4 cm grouping): a weak
 // component may hold several clusters, found one after the other by the serial algorithm (seeds in ascending index
 // order, each cluster = what its seed reaches among the still unvisited points).  Restated without the order: a point
@@ -1203,10 +1615,13 @@ __global__ void bfs_emit_kernel(int N, const int *__restrict__ counters, const i
     if (t == 0) cluster_offsets[counters[3]] = counters[4];
 }
 
+// 64-bit words of a node bitmap, padded to an even count (16-byte copies)
+inline int bm_words64(int N) { return ((N + 63) / 64 + 1) & ~1; }
+
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
         *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2], *defi, *left;
-    unsigned long long *vp, *cc, *tile_status, *amask;
+    unsigned long long *vp, *cc, *tile_status, *amask, *bits;
     int *cand, *cnt;
     void *scan_ws;
 };
@@ -1233,6 +1648,7 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.cand = take(nb); w.cnt = take(nb);
     w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / DIR_TILE + 2));
     w.amask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N * (MAX_SLICES + 1));
+    w.bits = (unsigned long long *)take(3 * sizeof(unsigned long long) * (size_t)bm_words64(N));   // bitmaps V, F, C
     w.counters = take(sizeof(int) * 16);
     w.scan_ws = take(ms3d_scan_workspace_bytes());
     return off;
@@ -1299,6 +1715,15 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     }
     DBG("after select");
     bool replay = true, dense = false, directed = false, stage2 = false;
+    // LDS-resident node bitmaps in the dense symmetric passes: up to ~1.1 M points (144 KB of bits per workgroup)
+    static const bool bm_on = [] { const char *e = getenv("MS3D_BFS_BITMAP"); return !e || atoi(e) != 0; }();
+    static const hipError_t bm_attr = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)glob_mark_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)glob_pull_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)glob_win_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        return e;
+    }();
+    const bool bitmaps = bm_on && bm_attr == hipSuccess && (size_t)bm_words64(N) * 8 <= 144 * 1024;
     const int wl_grid = ms3d_divup(N, 256);  // per-work-item kernels are launched for the upper bound N, they mask on nwork
     int level = 0;
     auto run_levels = [&](int nlev) -> int {
@@ -1314,6 +1739,27 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                 MS3D_LAUNCH_CHECK();
                 dir_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.claim, w.amask,
                                                            w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n]);
+                MS3D_LAUNCH_CHECK();
+                continue;
+            }
+            if (bitmaps) {
+                const int nw = bm_words64(N);
+                unsigned long long *Vb = w.bits, *Fb = w.bits + nw, *Cb = w.bits + 2 * (size_t)nw;
+                const size_t lds = (size_t)nw * 8;
+                glob_bits_kernel<<<nb, 256, 0, stream>>>(N, level, w.vp, Vb, Fb, Cb);
+                MS3D_LAUNCH_CHECK();
+                glob_mark_bm_kernel<<<256 * 2, BM_THREADS, lds, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters,
+                                                                        w.worklist, w.comp_base, w.done[c], w.done[n],
+                                                                        w.seg_start[c], w.seg_start[n], w.seg_cnt[c],
+                                                                        w.seg_cnt[n], w.cand, w.cnt, w.scratch_node,
+                                                                        w.scratch_seed, w.tile_status, Vb, nw);
+                MS3D_LAUNCH_CHECK();
+                glob_pull_bm_kernel<<<256 * 2, BM_THREADS, lds, stream>>>(N, level, ball_idx, start_len, w.vp, w.cand, w.cc, w.cnt,
+                                                                        w.counters, Fb, reinterpret_cast<unsigned *>(Cb), nw);
+                MS3D_LAUNCH_CHECK();
+                glob_win_bm_kernel<<<256 * 2, WIN_BM_THREADS, lds, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.cnt,
+                                                                       w.cc, w.vp, w.tile_status, Fn, w.seg_start[n],
+                                                                       w.seg_cnt[n], Cb, nw);
                 MS3D_LAUNCH_CHECK();
                 continue;
             }

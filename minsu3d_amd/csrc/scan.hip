@@ -124,28 +124,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const int *i
     local = wave_sum(local);
     if (lane_id() == 0) s_wave[wave_id()] = local;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wave_id() == 0) {
+        const int l = lane_id();
         int total = 0;
 #pragma unroll
         for (int w = 0; w < SCAN_THREADS / 64; w++) total += s_wave[w];
         int prefix = 0;
         if (bid == 0) {
-            __hip_atomic_store(&st->status[0], SCAN_PREFIX | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0)
+                __hip_atomic_store(&st->status[0], SCAN_PREFIX | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(&st->status[bid], SCAN_AGG | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int j = bid - 1;; j--) {          // every lower ticket is running or done: the wait ends
-                unsigned long long w;
-                do {
-                    w = __hip_atomic_load(&st->status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((w >> 32) == 0);
-                prefix += (int)(unsigned)w;
-                if ((w >> 32) == (SCAN_PREFIX >> 32)) break;
+            if (l == 0)
+                __hip_atomic_store(&st->status[bid], SCAN_AGG | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look-back, 64 predecessors per step (round 5; one thread walking back word by word paid a memory-side
+            // round trip per predecessor: 35-75 us per scan inside the ball-query / clustering chains): the aggregates down
+            // to the nearest span whose inclusive prefix is known are summed; every lower ticket is running or done, so the
+            // wait ends
+            for (int hi = bid - 1; hi >= 0;) {
+                const int t = hi - l;
+                const unsigned long long w = t >= 0 ? __hip_atomic_load(&st->status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                    : SCAN_PREFIX;
+                const unsigned long long incl_m = __ballot((w >> 32) == (SCAN_PREFIX >> 32)), inval_m = __ballot((w >> 32) == 0ull);
+                const int first = incl_m ? __ffsll((long long)incl_m) - 1 : 64;
+                const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                if (inval_m & need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                prefix += wave_sum(l <= first ? (int)(unsigned)w : 0);
+                if (first < 64) break;
+                hi -= 64;
             }
-            __hip_atomic_store(&st->status[bid], SCAN_PREFIX | (unsigned)(prefix + total), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0)
+                __hip_atomic_store(&st->status[bid], SCAN_PREFIX | (unsigned)(prefix + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_carry = prefix;
-        if (bid == nspans - 1 && total_out) *total_out = prefix + total;
+        if (l == 0) {
+            s_carry = prefix;
+            if (bid == nspans - 1 && total_out) *total_out = prefix + total;
+        }
     }
     __syncthreads();
     int carry = s_carry;

@@ -16,6 +16,39 @@ from ..loss import PTOffsetLoss
 from .module import Backbone
 
 
+class _HandOverGradsFn(torch.autograd.Function):
+    """The three per-point losses again, as a node whose backward HANDS OVER gradients that were computed earlier
+    (GeneralModel._early_point_backward) instead of computing them: d(l0 + l1 + l2) / d(point features, head parameters),
+    scaled by the upstream gradient.  The early result is exact whenever the three losses receive the SAME upstream
+    gradient tensor (loss = sum(losses.values()), with or without a common factor: autograd hands one tensor to all
+    terms of a sum, which is checked by storage address -- no device round trip); otherwise (weighted losses, a loss left
+    out) the gradients are computed the ordinary way through the graph that was kept."""
+
+    @staticmethod
+    def forward(ctx, pack, pf, *params):
+        ctx.pack = pack
+        ctx.set_materialize_grads(False)
+        return tuple(l.detach() for l in pack["losses"])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        pack, ctx.pack = ctx.pack, None
+        n = len(pack["grads"])
+        if all(g is None for g in gs):
+            return (None,) * (1 + n)
+        same = all(g is not None and g.numel() == 1 and g.data_ptr() == gs[0].data_ptr() for g in gs)
+        if same and pack["grads"] is not None:
+            s = gs[0].reshape(())
+            return (None,) + tuple(None if g is None else g * s for g in pack["grads"])
+        # the general case: a fresh evaluation of the losses (the fused loss node scales its gradients in place and can
+        # run once) on the heads' graph, which the early pass kept
+        with torch.enable_grad():
+            fresh = list(pack["recompute"]().values())
+        gl = [(f, g) for f, g in zip(fresh, gs) if g is not None]
+        grads = torch.autograd.grad([f for f, _ in gl], pack["inputs"], grad_outputs=[g for _, g in gl], allow_unused=True)
+        return (None,) + tuple(grads)
+
+
 class GeneralModel(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -74,6 +107,39 @@ class GeneralModel(nn.Module):
         for every launch.  `_loss` picks the result up."""
         if torch.is_grad_enabled() and "sem_labels" in data_dict and "instance_center_xyz" in data_dict:
             output_dict["_point_losses"] = self._point_losses(data_dict, output_dict)
+
+    def _early_point_backward(self, data_dict, output_dict):
+        """Scheduling only (round 5): the backward of the per-point heads and losses -- ~1.2 ms of bandwidth-bound kernels
+        over all points that nothing in the grouping / proposal branch feeds -- is queued HERE, right behind the grouping's
+        last host round trip, where the GPU has run dry and idles ~1.7 ms while the interpreter issues the proposal
+        network's ~160 small launches (profiles/r04_step_timeline.txt), instead of at the start of the GPU-bound backward
+        pass.  The gradients are handed to autograd by _HandOverGradsFn when the real backward pass arrives; the losses'
+        values, the heads' graph (for anybody who differentiates the scores directly) and every parameter gradient are
+        what they would have been.
+        OFF by default (MS3D_EARLY_HEADS=1 turns it on): measured, it buys nothing (profiles/r05_experiments.txt): the
+        heads' backward is ~0.6 ms of kernels issued through ~80 autograd nodes, i.e. ~0.7 ms of interpreter time that moves
+        from the GPU-bound backward pass (where the host is milliseconds ahead) into this host-bound stretch -- the step
+        stays at 20.0 ms either way.  Kept as a tested option for a host whose launch path is cheaper."""
+        losses = output_dict.get("_point_losses")
+        pf = output_dict.get("point_features")
+        if (losses is None or pf is None or not pf.requires_grad or not torch.is_grad_enabled()
+                or os.environ.get("MS3D_EARLY_HEADS", "0") != "1"):
+            return
+        keys, vals = list(losses.keys()), list(losses.values())
+        if any(v.grad_fn is None for v in vals):
+            return
+        heads = [getattr(self.backbone, n, None) for n in ("semantic_branch", "offset_branch")]
+        if any(h is None for h in heads):           # a wrapped / replaced backbone: leave the step to autograd
+            return
+        params = [p for m in heads for p in m.parameters() if p.requires_grad]
+        inputs = [pf] + params
+        total = vals[0]
+        for v in vals[1:]:
+            total = total + v
+        grads = torch.autograd.grad(total, inputs, retain_graph=True, allow_unused=True)
+        pack = {"losses": vals, "grads": grads, "inputs": inputs,
+                "recompute": lambda d=data_dict, o=output_dict: self._point_losses(d, o)}
+        output_dict["_point_losses"] = dict(zip(keys, _HandOverGradsFn.apply(pack, *inputs)))
 
     def _loss(self, data_dict, output_dict):
         queued = output_dict.pop("_point_losses", None)

@@ -52,6 +52,7 @@ class HAIS(GeneralModel):
             z = out["point_features"].new_zeros((0, 1))
             out["proposal_scores"] = (z, proposals_idx, proposals_offset, z)
             return out
+        self._early_point_backward(data_dict, out)     # fills the GPU while the proposal branch is being issued
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"], data_dict["point_xyz"],
                                          net.score_scale, net.score_fullscale, self.device, rand=self.voxelization_rand,
                                          max_dup=1)                 # a point belongs to at most one aggregated cluster

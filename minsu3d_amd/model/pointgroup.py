@@ -94,6 +94,7 @@ class PointGroup(GeneralModel):
         if proposals_offset.numel() <= 1:                      # nothing grouped (the reference would crash here)
             out["proposal_scores"] = (out["point_features"].new_zeros((0, 1)), proposals_idx, proposals_offset)
             return out
+        self._early_point_backward(data_dict, out)     # fills the GPU while the proposal branch is being issued
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"],
                                          data_dict["point_xyz"], net.score_scale, net.score_fullscale, self.device,
                                          rand=self.voxelization_rand, max_dup=2)   # a point: <= one cluster per grouping

@@ -110,6 +110,7 @@ class SoftGroup(GeneralModel):
         out["proposals_idx"], out["proposals_offset"] = proposals_idx, proposals_offset
         if proposals_offset.numel() <= 1:
             return out
+        self._early_point_backward(data_dict, out)     # fills the GPU while the proposal branch is being issued
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"], data_dict["point_xyz"],
                                          net.instance_voxel_cfg.scale, net.instance_voxel_cfg.spatial_shape, self.device,
                                          rand=self.voxelization_rand)

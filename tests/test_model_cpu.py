@@ -310,3 +310,54 @@ def test_skip_gradient_through_the_first_convolution_equals_autograd(cpu_backend
         assert fused.keys() == plain.keys()
         for n in fused:
             assert torch.allclose(fused[n], plain[n], rtol=1e-6, atol=1e-9), (n, freeze_bn)
+
+
+@pytest.mark.parametrize("name", ["pointgroup", "hais", "softgroup"])
+def test_early_head_backward_hands_over_the_same_gradients(cpu_backend, monkeypatch, name):
+    """GeneralModel._early_point_backward (scheduling: the heads' backward is queued behind the grouping, its gradients
+    handed to autograd later) against the ordinary backward pass: identical parameter gradients for loss = sum(losses)
+    (also with a common factor), and through the general path -- unequal loss weights, a loss left out -- too"""
+    model = _build(name, seed=2)
+    model.hparams.cfg.data.point_num_avg = [-1, -1] + [400.0] * 18
+    model.hparams.cfg.data.radius_avg = [-1.0, -1.0] + [0.3] * 18
+    model.voxelization_rand = (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3]))
+    batch = small_batch((13, 14))
+    if name == "softgroup":
+        n = batch["point_xyz"].size(0)
+        sem = torch.full((n, 20), 0.01)
+        sem[torch.arange(n), batch["grouping_semantic_preds"].long()] = 0.8
+        batch["grouping_semantic_scores"] = sem
+    model.train()
+
+    def grads(early, combine):
+        monkeypatch.setenv("MS3D_EARLY_HEADS", "1" if early else "0")
+        model.zero_grad(set_to_none=True)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        losses = model._loss(batch, model(batch))
+        combine(losses).backward()
+        model.load_state_dict(sd)                 # running statistics back: both evaluations see the same module state
+        return {n_: p.grad.detach().clone() for n_, p in model.named_parameters() if p.grad is not None}
+
+    seen = []
+    from minsu3d_amd.model import general_model as gm
+    real = gm._HandOverGradsFn.apply
+    monkeypatch.setattr(gm._HandOverGradsFn, "apply", staticmethod(lambda *a: (seen.append(1), real(*a))[1]))
+    weights = {"semantic_loss": 0.7, "offset_norm_loss": 1.3, "offset_dir_loss": 0.4}
+    for label, combine, exact in (
+            ("sum", lambda l: sum(l.values()), True),
+            ("scaled sum", lambda l: sum(l.values()) / 4, True),
+            ("weighted", lambda l: sum(weights.get(k, 1.0) * v for k, v in l.items()), False),
+            ("one left out", lambda l: sum(v for k, v in l.items() if k != "offset_dir_loss"), False)):
+        n0 = len(seen)
+        want = grads(False, combine)
+        assert len(seen) == n0
+        got = grads(True, combine)
+        assert len(seen) == n0 + 1, label                       # the early pass ran
+        assert got.keys() == want.keys()
+        for k in want:
+            if exact and ("semantic_branch" in k or "offset_branch" in k):
+                assert torch.equal(got[k], want[k]), (label, k)       # the heads' own gradients: the same numbers
+            else:
+                # below the heads the two branches' contributions to d(point features) meet in another order:
+                # (score + sem) + off against score + (sem + off)
+                assert torch.allclose(got[k], want[k], rtol=1e-4, atol=2e-6 * float(want[k].abs().max())), (label, k)
