@@ -47,8 +47,13 @@ int ms3d_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz
  * the 1000-neighbour cap bites.  cluster_idxs has capacity [N,2], cluster_offsets [N+1];
  * counts[0] = nCluster, counts[1] = sumNPoint are returned to the [host]. */
 size_t ms3d_bfs_workspace_bytes(int N);
-/* capped_hint: what ms3d_ballquery_batch_p reported for this graph (0 = no list reached 1000 -> symmetric graph,
- * 1 = some did, -1 = unknown: decided on the device at the price of one host sync) */
+/* capped_hint: what ms3d_ballquery_batch_p reported for this graph: 0 = no list reached 1000 -> symmetric graph with
+ * ascending lists that contain the point itself; 1 = some did (directed: a capped list holds the point's lowest-index
+ * neighbours).  -1 = NOBODY VOUCHES for the graph -- any adjacency lists, as the reference's host BFS accepts them
+ * (bfs_cluster.cpp:28-54): nothing is assumed (no symmetry, no order inside a list, lists laid out in any order, any
+ * length), at the price of a validation pass and two host syncs.  Then MS3D_E_UNSUPPORTED is returned -- instead of a
+ * wrong answer or an out-of-bounds read -- for a list header outside [0, n_edges], a target outside [0, N), or a list that
+ * names one neighbour twice (the serial loop skips the second mention; the parallel claims cannot). */
 int ms3d_pg_bfs_cluster(const int16_t *semantic_label, const int *ball_query_idxs, long n_edges /* = nActive */,
                         const int *start_len, int N, int threshold, int capped_hint, int *cluster_idxs, int *cluster_offsets, int *counts /*[host,2]*/,
                         void *workspace, size_t workspace_bytes, ms3d_stream_t stream);

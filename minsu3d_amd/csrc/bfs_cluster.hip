@@ -32,6 +32,7 @@
 // (nCluster, sumNPoint) read the caller needs to size its tensors.
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 #include "common.h"
 #include "scan.h"
@@ -107,7 +108,7 @@ __global__ void bfs_init_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
         scratch_seed[N + i] = -1;
         defi[i] = 0;
     }
-    if (i < 16) counters[i] = 0;
+    if (i < 32) counters[i] = 0;
 }
 
 // Weak components in three steps (the atomics of a union cost ~30x a cached gather on this part -- 5.7 G/s against
@@ -129,7 +130,7 @@ __global__ void bfs_link_kernel(int N, Thr thr, const int16_t *__restrict__ sem,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
-    if (ln <= 1) return;
+    if (ln < 1) return;   // (a one-entry list is the point itself in a ball query's graph, but not in anybody's: linked like the rest)
     const unsigned h1 = ((unsigned)i * 0x9E3779B1u) >> 8, h2 = (((unsigned)i ^ 0x5bd1e995u) * 0x85ebca6bu) >> 8;
     const int j1 = ball_idx[st + (int)(h1 % (unsigned)ln)], j2 = ball_idx[st + (int)(h2 % (unsigned)ln)];
     const int lab = thr.mode == 0 ? (int)sem[i] : 0;
@@ -195,7 +196,9 @@ __global__ __launch_bounds__(256) void bfs_hook_kernel(int N, Thr thr, int symme
         const int st = hA.st, ln = hA.ln, lab = hA.lab;
         int ri = hA.ri;         // compressed: the root as of the last compress pass
         // four 64-edge slices per trip: the index loads, then the parent gathers are in flight together
-        for (int t0 = 0; t0 < ln && ln > 1; t0 += 256) {
+        // (a one-entry list of a graph a ball query vouches for is the point itself; of any other graph it may be an edge:
+        // rounds 1-4 skipped it either way, which cut such points out of their component -- found by the random-digraph test)
+        for (int t0 = 0; t0 < ln && ln > (symmetric ? 1 : 0); t0 += 256) {
             int j[4], pj[4];
             if (t0 == 0) {
 #pragma unroll
@@ -263,6 +266,25 @@ __global__ void bfs_flatten_kernel(int N, int *parent, int *root, int *comp_size
     // a list cut at the cap makes the graph directed (bfs_cluster.cu:38-43): only then can a weak component
     // hold more than one cluster, and only then is the order-by-replay kernel required
     if (start_len[i * 2 + 1] >= 1000 && counters[5] == 0) atomicOr(&counters[5], 1);
+    // longer than the edge masks of the chip-wide directed expansion cover (never from a ball query: it stops at 1000)
+    if (start_len[i * 2 + 1] > 1024 && counters[18] == 0) atomicOr(&counters[18], 1);
+}
+
+// strict mode, before anything dereferences the lists: every header inside the edge array, every target a point
+__global__ void bfs_validate_kernel(int N, long n_edges, const int *__restrict__ ball_idx, const int *__restrict__ start_len,
+                                    int *flag)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (t < N) {
+        const long st = start_len[t * 2], ln = start_len[t * 2 + 1];
+        bad = st < 0 || ln < 0 || st + ln > n_edges;
+    }
+    for (long e = t; e < n_edges; e += (long)gridDim.x * blockDim.x) {
+        const int j = ball_idx[e];
+        bad |= j < 0 || j >= N;
+    }
+    if (__ballot(bad) && lane_id() == 0) *flag = 1;
 }
 
 __global__ void bfs_select_kernel(int N, Thr thr, const int *__restrict__ root, const int *__restrict__ comp_size,
@@ -309,8 +331,13 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
     int N, Thr thr, const int16_t *__restrict__ sem, const int *__restrict__ ball_idx,
     const int *__restrict__ start_len, const int *__restrict__ root, const int *__restrict__ comp_size,
     const int *__restrict__ worklist, int *counters, int *visited, int *claim, int *scratch_node, int *scratch_seed,
-    int *cl_size, int *cl_start)
+    int *cl_size, int *cl_start, int *guard /* strict mode: zeroed [N], else NULL */)
 {
+    // strict (a graph no ball query of ours vouches for): a list that names one neighbour twice would emit it twice (both
+    // edges carry the winning claim; the serial loop skips the second) -- every emission also exchanges a word of `guard`
+    // (its own array: the visited flags are read with plain cached loads, which an L2 atomic does not refresh) and a second
+    // emission raises counters[17]: the call fails instead of returning a cluster with a repeated member
+    const bool strict = guard != nullptr;
     __shared__ int s_pref[NT + 1];
     __shared__ int s_st[NT];
     __shared__ int s_cnt[NT];
@@ -426,6 +453,7 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                             if (win) {
                                 scratch_node[new_tail + rank] = j;
                                 scratch_seed[new_tail + rank] = seed;
+                                if (strict && atomicExch(&guard[j], 1) == 1) counters[17] = 1;
                                 visited[j] = 1;
                                 if (rank < NT) {   // (tot <= E <= NT)
                                     s_fst[fbuf ^ 1][rank] = hdr.x;
@@ -520,7 +548,10 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                             }
                             __syncthreads();
                             // mark the winners visited only now: phase B2 of another wave must still see them unvisited
-                            for (int o = new_tail + tid; o < new_tail + tot; o += NT) visited[scratch_node[o]] = 1;
+                            for (int o = new_tail + tid; o < new_tail + tot; o += NT) {
+                                if (strict && atomicExch(&guard[scratch_node[o]], 1) == 1) counters[17] = 1;
+                                visited[scratch_node[o]] = 1;
+                            }
                             new_tail += tot;
                         }
                         __syncthreads();
@@ -573,6 +604,7 @@ __global__ __launch_bounds__(NT) void bfs_expand_kernel(
                             if (win) {
                                 scratch_node[new_tail + rank] = j;
                                 scratch_seed[new_tail + rank] = seed;
+                                if (strict && atomicExch(&guard[j], 1) == 1) counters[17] = 1;
                                 visited[j] = 1;
                             }
                             new_tail += tot;
@@ -1282,7 +1314,12 @@ __global__ void dir_init_kernel(const int *__restrict__ worklist, const int *__r
 }
 
 // first mask slot of a node's list: strictly increasing with the node, never shared between two nodes
-__device__ __forceinline__ long mask_slot(int st, int node) { return (long)(st >> 6) + node; }
+// (canonical lists: start = exclusive prefix sum of the lengths in point order; a graph nobody vouches for -- strict -- may
+// order its lists anyhow, e.g. the reference's own ball query hands out starts in atomic order: a fixed stride per node then)
+__device__ __forceinline__ long mask_slot(int st, int node, int strict = 0)
+{
+    return strict ? (long)node * MAX_SLICES : (long)(st >> 6) + node;
+}
 
 template <bool GROUPS>   // stage 2: an edge counts only inside one label group (root[] holds the labels then)
 __global__ __launch_bounds__(256) void dir_claim_kernel(
@@ -1291,7 +1328,7 @@ __global__ __launch_bounds__(256) void dir_claim_kernel(
     const int *__restrict__ worklist, const int *__restrict__ comp_base, const int *__restrict__ done_cur, int *done_next,
     const int *__restrict__ seg_start_cur, int *seg_start_next, const int *__restrict__ seg_cnt_cur, int *seg_cnt_next,
     int *claim, int *scratch_node, int *scratch_seed, unsigned long long *__restrict__ amask,
-    unsigned long long *tile_status)
+    unsigned long long *tile_status, int strict)
 {
     const int nF = counters[6 + (level & 1)];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -1321,7 +1358,7 @@ __global__ __launch_bounds__(256) void dir_claim_kernel(
         }
         const int st = start_len[node * 2], ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);  // canonical lists: <= 1000
         const int lab = thr.mode == 0 ? (int)sem[node] : 0;
-        unsigned long long *am = amask + mask_slot(st, node);
+        unsigned long long *am = amask + mask_slot(st, node, strict);
         // four 64-edge slices per trip: the four index loads, then the four claim gathers are in flight together
         for (int t0 = 0; t0 < ln; t0 += 256) {
             int j[4], c[4];
@@ -1362,7 +1399,7 @@ __global__ __launch_bounds__(256) void dir_win_kernel(int level, const int *__re
                                                        int *counters, int *claim,
                                                        const unsigned long long *__restrict__ amask,
                                                        unsigned long long *tile_status, int *F_next, int *seg_start_next,
-                                                       int *seg_cnt_next)
+                                                       int *seg_cnt_next, int strict, int *guard)
 {
     __shared__ unsigned long long s_wm[DIR_TILE][MAX_SLICES];
     __shared__ int s_cnt[DIR_TILE];
@@ -1398,7 +1435,7 @@ __global__ __launch_bounds__(256) void dir_win_kernel(int level, const int *__re
             if (pos < nF) {
                 const int node = s_node[q];
                 const int st = s_st[q], ln = s_ln[q];
-                const unsigned long long *am = amask + mask_slot(st, node);
+                const unsigned long long *am = amask + mask_slot(st, node, strict);
                 const int nsl = (ln + 63) >> 6;
                 const unsigned long long mine = l < nsl ? am[l] : 0ull;   // all slice masks of the list in one load
                 for (int c0 = 0; c0 < nsl; c0 += 4) {   // four slices in flight: index gathers, then claim gathers
@@ -1478,6 +1515,8 @@ __global__ __launch_bounds__(256) void dir_win_kernel(int level, const int *__re
                 if ((wm >> l) & 1ull) {
                     const int j = ball_idx[st + 64 * c + l];
                     F_next[out + __popcll(wm & ((1ull << l) - 1ull))] = j;
+                    // strict (see bfs_expand_kernel): a neighbour named twice in one list would be emitted twice
+                    if (guard && atomicExch(&guard[j], 1) == 1) counters[17] = 1;
                     claim[j] = -1;  // visited
                 }
                 out += __popcll(wm);
@@ -1620,7 +1659,7 @@ inline int bm_words64(int N) { return ((N + 63) / 64 + 1) & ~1; }
 
 struct BfsWorkspace {
     int *parent, *root, *comp_size, *visited, *claim, *worklist, *scratch_node, *scratch_seed, *cl_size, *cl_start, *keep,
-        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2], *defi, *left;
+        *keep_size, *cid, *out_off, *counters, *Fa, *Fb, *comp_base, *done[2], *seg_start[2], *seg_cnt[2], *defi, *left, *guard;
     unsigned long long *vp, *cc, *tile_status, *amask, *bits;
     int *cand, *cnt;
     void *scan_ws;
@@ -1636,7 +1675,7 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     const size_t nb = sizeof(int) * (size_t)N;
     w.parent = take(nb); w.root = take(nb); w.comp_size = take(nb); w.visited = take(nb); w.claim = take(nb); w.worklist = take(nb);
     w.scratch_node = take(2 * nb); w.scratch_seed = take(2 * nb); w.cl_size = take(nb); w.cl_start = take(nb);
-    w.defi = take(nb); w.left = take(nb);
+    w.defi = take(nb); w.left = take(nb); w.guard = take(nb);
     w.keep = take(nb); w.keep_size = take(nb); w.cid = take(nb); w.out_off = take(nb);
     // chip-wide expansion: frontier double buffer, per-component bookkeeping double-buffered by level parity, one
     // node words / candidate tags / claims / child counts, scan state per tile of 64 positions
@@ -1649,7 +1688,7 @@ size_t carve(BfsWorkspace &w, int N, void *base)
     w.tile_status = (unsigned long long *)take(sizeof(unsigned long long) * ((size_t)N / DIR_TILE + 2));
     w.amask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)N * (MAX_SLICES + 1));
     w.bits = (unsigned long long *)take(3 * sizeof(unsigned long long) * (size_t)bm_words64(N));   // bitmaps V, F, C
-    w.counters = take(sizeof(int) * 16);
+    w.counters = take(sizeof(int) * 64);   // [0..15] as documented at the kernels, [17] repeated member, [18] list > 1024, [32] validation
     w.scan_ws = take(ms3d_scan_workspace_bytes());
     return off;
 }
@@ -1676,6 +1715,26 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
     BfsWorkspace w;
     if (carve(w, N, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
     const int nb = ms3d_divup(N, 256);
+    // capped_hint < 0: nobody vouches for this graph (round 5; the reference's host BFS accepts ANY adjacency lists,
+    // bfs_cluster.cpp:28-54).  Then nothing is assumed about it: the lists are validated first (headers inside the edge
+    // array, targets inside [0, N): MS3D_E_UNSUPPORTED otherwise -- the reference would read out of bounds), no symmetry
+    // is assumed (a dense graph takes the chip-wide DIRECTED expansion, which is out-edge reachability from ascending seeds
+    // for any graph; lists beyond 1024 entries take the per-component replay), and a neighbour named twice in one list
+    // (which the serial loop skips and the parallel claims would emit twice) fails the call.
+    const bool strict = capped_hint < 0;
+    if (strict) {
+        int bad = 0;
+        MS3D_CHECK(hipMemsetAsync(w.counters + 32, 0, sizeof(int), stream));
+        const long work = n_edges > N ? n_edges : N;
+        bfs_validate_kernel<<<(int)std::min<long>((work + 255) / 256, 256 * 16), 256, 0, stream>>>(N, n_edges, ball_idx, start_len,
+                                                                                                  w.counters + 32);
+        MS3D_LAUNCH_CHECK();
+        MS3D_CHECK(hipMemcpyAsync(&bad, w.counters + 32, sizeof(int), hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipStreamSynchronize(stream));
+        if (bad) { if (getenv("MS3D_DEBUG")) fprintf(stderr, "[bfs] validation failed\n"); return MS3D_E_UNSUPPORTED; }
+        MS3D_CHECK(hipMemsetAsync(w.guard, 0, sizeof(int) * (size_t)N, stream));
+    }
+    int *guard = strict ? w.guard : nullptr;
     // weak components, their sizes, and the work list of the components that can hold a qualifying cluster
     auto prepare = [&]() -> int {
         bfs_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.parent, w.comp_size, w.visited, w.claim,
@@ -1735,10 +1794,11 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                 claim_fn<<<256 * 8, 256, 0, stream>>>(thr, level, sem, ball_idx, start_len, w.root, Fc, w.counters,
                                                              w.worklist, w.comp_base, w.done[c], w.done[n], w.seg_start[c],
                                                              w.seg_start[n], w.seg_cnt[c], w.seg_cnt[n], w.claim,
-                                                             w.scratch_node, w.scratch_seed, w.amask, w.tile_status);
+                                                             w.scratch_node, w.scratch_seed, w.amask, w.tile_status,
+                                                             strict ? 1 : 0);
                 MS3D_LAUNCH_CHECK();
                 dir_win_kernel<<<256 * 8, 256, 0, stream>>>(level, ball_idx, start_len, w.root, Fc, w.counters, w.claim, w.amask,
-                                                           w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n]);
+                                                           w.tile_status, Fn, w.seg_start[n], w.seg_cnt[n], strict ? 1 : 0, guard);
                 MS3D_LAUNCH_CHECK();
                 continue;
             }
@@ -1777,27 +1837,32 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         return 0;
     };
     auto launch_replay = [&]() -> int {
-        if (n_edges >= (long)N * 24)
+        static const int force_nt = [] { const char *e = getenv("MS3D_BFS_REPLAY_NT"); return e ? atoi(e) : 0; }();
+        if (force_nt == 1024 || (force_nt == 0 && n_edges >= (long)N * 24))
             bfs_expand_kernel<1024><<<256 * 2, 1024, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
                                                               w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
+                                                              w.scratch_seed, w.cl_size, w.cl_start, guard);
         else
             bfs_expand_kernel<512><<<256 * 2, 512, 0, stream>>>(N, thr, sem, ball_idx, start_len, w.root, w.comp_size,
                                                               w.worklist, w.counters, w.visited, w.claim, w.scratch_node,
-                                                              w.scratch_seed, w.cl_size, w.cl_start);
+                                                              w.scratch_seed, w.cl_size, w.cl_start, guard);
         MS3D_LAUNCH_CHECK();
         return 0;
     };
     static const bool dir_on = [] { const char *e = getenv("MS3D_BFS_DIRECTED"); return !e || atoi(e) != 0; }();
     if (n_edges >= (long)N * 24) {
         int capped = capped_hint;
-        if (capped < 0) {
-            int h[8];
-            MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        bool too_long = false;
+        if (strict) {
+            int h[32];
+            MS3D_CHECK(hipMemcpyAsync(h, w.counters, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
             MS3D_CHECK(hipStreamSynchronize(stream));
-            capped = h[5];
+            capped = 1;               // unknown symmetry: the directed expansion is right for any graph
+            too_long = h[18] != 0;    // ... unless a list outgrows its edge masks: the replay
         }
-        if (capped == 0) {
+        if (too_long) {
+            // (replay stays true)
+        } else if (capped == 0) {
             replay = false;
             dense = true;
             glob_vp_init_kernel<<<nb, 256, 0, stream>>>(N, thr, sem, w.vp, w.cand, w.cc);
@@ -1818,7 +1883,7 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
         const int rc2 = launch_replay();
         if (rc2) return rc2;
     }
-    int host[16];
+    int host[32];
     for (;;) {
         if (dense) {
             // the levels are launched speculatively (a shifted-coordinate blob is exhausted after ~10) and the frontier
@@ -1853,8 +1918,12 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                                                w.out_off, w.keep_size, cluster_idxs, cluster_offsets);
         MS3D_LAUNCH_CHECK();
         DBG("after emit");
-        MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
+        MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
         MS3D_CHECK(hipStreamSynchronize(stream));
+        if (strict && host[17]) {                                 // a neighbour named twice in one list
+            if (dbg) fprintf(stderr, "[bfs] repeated member flagged\n");
+            return MS3D_E_UNSUPPORTED;
+        }
         if (dbg) fprintf(stderr, "[bfs] counters %d %d %d %d %d %d %d %d | %d %d level=%d\n", host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8], host[9], level);
         if (dense) {
             if (host[6 + (level & 1)] == 0) {       // frontier empty: every component was exhausted
@@ -1878,7 +1947,7 @@ int bfs_run(Thr thr, int capped_hint, const int16_t *sem, const int *ball_idx, l
                                                                       w.counters);
                     MS3D_LAUNCH_CHECK();
                 }
-                MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
+                MS3D_CHECK(hipMemcpyAsync(host, w.counters, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
                 MS3D_CHECK(hipStreamSynchronize(stream));
                 if (host[11 + ((round - 1) & 1)] == 0) break;   // the last round moved nothing: fixed point
             }

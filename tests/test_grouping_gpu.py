@@ -443,3 +443,95 @@ def test_single_launch_scan_matches_cumsum(n):
     torch.cuda.synchronize()
     for out, total in outs:
         assert torch.equal(out.long(), want) and int(total) == int(want[-1] + x[-1])
+
+
+def _random_digraph(rng, n, deg_lo, deg_hi, shuffle_lists, shuffle_starts, local=None, down_frac=0.0):
+    """adjacency lists nobody's ball query made: random out-neighbours (no symmetry), optionally unsorted lists and
+    start offsets in arbitrary order (the reference's own ball query hands them out in atomic order).
+    down_frac: that share of the points only names points BELOW itself -- ascending seeds cannot reach them from below,
+    so a dense graph falls into many clusters whose membership and order the serial seed order decides"""
+    lists = []
+    for i in range(n):
+        d = int(rng.integers(deg_lo, deg_hi + 1))
+        pool = n if local is None else min(n, local)
+        base = 0 if local is None else max(0, min(n - pool, i - pool // 2))
+        if rng.random() < down_frac:
+            base, pool = max(0, i - pool), min(pool, i) + 1
+        tgt = base + rng.choice(pool, min(d, pool), replace=False)
+        if rng.random() < 0.8:
+            tgt = np.unique(np.append(tgt, i))            # most points list themselves, like a ball query's
+        else:
+            tgt = np.unique(tgt)
+        if shuffle_lists:
+            rng.shuffle(tgt)
+        lists.append(tgt.astype(np.int32))
+    order = rng.permutation(n) if shuffle_starts else np.arange(n)
+    sl = np.zeros((n, 2), np.int32)
+    pos = 0
+    chunks = []
+    for i in order:
+        sl[i] = (pos, len(lists[i]))
+        chunks.append(lists[i])
+        pos += len(lists[i])
+    return np.concatenate(chunks), sl
+
+
+@pytest.mark.parametrize("n,deg,shuffle_lists,shuffle_starts,local,down", [
+    (4000, (0, 3), False, False, None, 0.0),     # sparse, directed: the per-component replay
+    (4000, (1, 4), True, True, None, 0.3),       # ... unsorted lists, lists laid out in arbitrary order
+    (3000, (30, 60), False, False, 400, 0.0),    # dense (>= 24 edges per point), directed, NOT capped: was taken for symmetric
+    (3000, (30, 60), True, True, 400, 0.97),     # ... unsorted, arbitrary layout, hundreds of clusters decided by the seed order
+    (6000, (25, 40), False, True, 300, 0.9),
+    (2500, (40, 1100), False, True, 1500, 0.9),  # lists beyond 1024 entries: the replay instead of the masked expansion
+])
+def test_bfs_on_arbitrary_directed_adjacency(be, oracle, n, deg, shuffle_lists, shuffle_starts, local, down):
+    """pg / sg_bfs_cluster through the operator boundary on graphs NO ball query made.  The reference's host
+    BFS accepts any adjacency lists (bfs_cluster.cpp:28-54: out-edge reachability from ascending seeds, members in FIFO
+    order); rounds 1-4 silently assumed a symmetric graph whenever no list sat at the 1000 cap.  Without a hint from our own
+    ball query nothing is assumed any more: bit-exact against the oracle -- and against the reference's OWN compiled
+    bfs_cluster.cpp where oracle/_ref is built -- clusters, member order, offsets."""
+    rng = np.random.default_rng(n + deg[1] + 7 * shuffle_lists)
+    idx, sl = _random_digraph(rng, n, deg[0], deg[1], shuffle_lists, shuffle_starts, local, down)
+    sem = rng.integers(2, 4, n).astype(np.int16)
+    for thr in (1, 3):
+        want = oracle.pg_bfs_cluster(sem, idx, sl, thr)
+        if oracle.ref() is not None:
+            live = oracle.pg_bfs_cluster(sem, idx, sl, thr, use_ref=True)
+            assert np.array_equal(live[0].reshape(-1, 2), want[0].reshape(-1, 2)) and np.array_equal(live[1], want[1])
+        a, o = be.pg_bfs_cluster(dev(sem), dev(idx), dev(sl), thr)
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+    mean = [-1.0, 30.0, 100.0]
+    for cid in range(3):
+        want = oracle.sg_bfs_cluster(mean, idx, sl, 0.05, cid)
+        a, o = be.sg_bfs_cluster(mean, dev(idx), dev(sl), 0.05, cid)
+        assert np.array_equal(o.cpu().numpy(), want[1])
+        assert np.array_equal(a.cpu().numpy().reshape(-1, 2), want[0].reshape(-1, 2))
+
+
+def test_bfs_rejects_lists_it_cannot_cluster(be):
+    """what the operator refuses instead of answering wrongly (the extension turns the code into an exception): a target
+    outside [0, N), a list header outside the edge array, and a list that names one neighbour twice (the serial loop skips
+    the second mention; the parallel claims would emit the member twice)"""
+    from minsu3d_amd._lib import HipLibraryError
+    rng = np.random.default_rng(3)
+    n = 2000
+    idx, sl = _random_digraph(rng, n, 2, 5, False, False)
+    sem = np.full(n, 2, np.int16)
+    be.pg_bfs_cluster(dev(sem), dev(idx), dev(sl), 1)                       # fine as it is
+    bad = idx.copy(); bad[17] = n
+    with pytest.raises(HipLibraryError):
+        be.pg_bfs_cluster(dev(sem), dev(bad), dev(sl), 1)
+    bad = idx.copy(); bad[5] = -3
+    with pytest.raises(HipLibraryError):
+        be.pg_bfs_cluster(dev(sem), dev(bad), dev(sl), 1)
+    bad_sl = sl.copy(); bad_sl[n - 1, 1] += 10
+    with pytest.raises(HipLibraryError):
+        be.pg_bfs_cluster(dev(sem), dev(idx), dev(bad_sl), 1)
+    # point 0 names point 1 twice, and point 1 is reached from 0 first
+    lists = [np.array([0, 1, 1], np.int32), np.array([1, 2], np.int32)] + [np.array([i], np.int32) for i in range(2, 40)]
+    sl2 = np.zeros((40, 2), np.int32)
+    sl2[:, 1] = [len(x) for x in lists]
+    sl2[1:, 0] = np.cumsum(sl2[:-1, 1])
+    with pytest.raises(HipLibraryError):
+        be.pg_bfs_cluster(dev(np.full(40, 2, np.int16)), dev(np.concatenate(lists)), dev(sl2), 1)
