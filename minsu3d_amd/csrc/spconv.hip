@@ -75,6 +75,7 @@ struct ConvArgs {
     const int *pl_tile_start;  // pair list of the table (ms3d_kmap_pairlist_build) or null
     const int *pl_entries;
     int dyn_picks;             // pair-list kernels: tiles picked off an LDS counter (MS3D_PL_DYNAMIC=1) instead of the fixed schedule
+    int k1_path;               // K = 1: bit 0 = accumulate_k1 in the LDS-resident table walk, bit 1 = in the small-level kernel
 };
 
 // ------------------------------------------------------------------ weight permutation
@@ -397,7 +398,8 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                 // the branch and wait on the spot (one L2 round trip per offset, 63 in a row on a 112-channel level).
                 // The fragments of UB offsets are requested together (explicit register arrays: left alone the
                 // scheduler keeps ~9 loads in flight, and a tiny level is exactly this chain of round trips).
-                constexpr int UB = NBT <= 2 ? GSZ : (NBT <= 4 ? 3 : 1);
+                constexpr int UB0 = NBT <= 2 ? GSZ : (NBT <= 4 ? 3 : 1);
+                constexpr int UB = UB0 < GSZ ? UB0 : GSZ;
 #pragma unroll
                 for (int u0 = 0; u0 < GSZ; u0 += UB) {
                     float wreg[UB][4][NBT];
@@ -432,6 +434,84 @@ __device__ __forceinline__ void accumulate_offsets(const ConvArgs &p, const floa
                             acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
                     }
                 }
+            }
+        }
+    }
+}
+
+// K = 1 (the 1x1 projections on the skip paths, the per-point Linear layers): one table entry per row, so the gather
+// parallelism the offset groups give the other layers has to come from the CHANNEL chunks -- four chunks of the row are
+// requested together, then multiplied.  (Round 5.  Through accumulate_offsets a K = 1 layer issued eight clamped dummy
+// gathers beside every real one, and the direct-B walk -- which multiplies every offset of its group, absent ones
+// included -- did 9x the loads and MFMAs: 128 -> 256 at 12k rows took 140 us.)
+template <int NBT, bool ALIGNED, bool DIRECT>
+__device__ __forceinline__ void accumulate_k1(const ConvArgs &p, const float *__restrict__ sW, int my_row, int q, int nb0,
+                                              f32x4 (&acc)[NBT])
+{
+    constexpr int CB = 4;   // chunks in flight
+    const int l = lane_id();
+    const bool row_ok = my_row >= 0 && my_row < p.Vout;
+    const int idx = row_ok ? p.nbr[my_row] : -1;
+    const int keep = ~(idx >> 31);
+    if (__ballot(idx >= 0) == 0ull) return;
+    const float *row = p.in + (size_t)max(idx, 0) * p.Cin + 4 * q;
+    for (int ch0 = 0; ch0 < p.NCH; ch0 += CB) {
+        f32x4 a[CB], sc[CB], sh[CB];
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int ch = min(ch0 + u, p.NCH - 1), c0 = 16 * ch + 4 * q;
+            if (ALIGNED) {
+                a[u] = *reinterpret_cast<const f32x4 *>(row + 16 * ch);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) a[u][t] = (c0 + t < p.Cin) ? row[16 * ch + t] : 0.f;
+            }
+            sc[u] = sh[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.pre_scale) {
+                if (ALIGNED) {
+                    sc[u] = *reinterpret_cast<const f32x4 *>(p.pre_scale + c0);
+                    sh[u] = *reinterpret_cast<const f32x4 *>(p.pre_shift + c0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        sc[u][t] = (c0 + t < p.Cin) ? p.pre_scale[c0 + t] : 0.f;
+                        sh[u][t] = (c0 + t < p.Cin) ? p.pre_shift[c0 + t] : 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            if (ch0 + u >= p.NCH) break;
+            const int ch = ch0 + u;
+            if (p.pre_scale) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float v = fmaf(a[u][t], sc[u][t], sh[u][t]);
+                    a[u][t] = p.pre_relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) a[u][t] = __int_as_float(__float_as_int(a[u][t]) & keep);
+            if (DIRECT) {
+                const float *w = p.wf + ((size_t)(ch * 4) * p.NBtot + nb0) * 64 + l;
+                float wreg[4][NBT];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) wreg[t][nb] = w[(size_t)(t * p.NBtot + nb) * 64];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], wreg[t][nb], acc[nb], 0, 0, 0);
+            } else {
+                const float *w = sW + (size_t)(ch * 4) * NBT * 64 + l;   // LDS image of this block's slice: [ch][t][nb][lane]
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], w[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
             }
         }
     }
@@ -556,7 +636,9 @@ __global__ __launch_bounds__(1024) void spconv_fwd_kernel(ConvArgs p)
             f32x4 acc[NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
+            // K = 1 (the 1x1 projections and the per-point Linear layers): accumulate_k1
+            if (p.K == 1 && (p.k1_path & 1)) accumulate_k1<NBT, ALIGNED, false>(p, sW, my_row, q, nb0, acc);
+            else accumulate_offsets<NBT, ALIGNED>(p, sW, 0, p.K, 0, my_row, q, nb0, acc);
             // a per-tile view of the arguments: the epilogue's per-column address arithmetic is loop invariant, and hoisted
             // out of this loop it stayed live across the offset loop -- in scratch (up to 390 bytes per lane)
             ConvArgs pt = p;
@@ -770,7 +852,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_small_kernel(ConvArgs p)
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int k_lo = wave_id() * OG, k_hi = min(p.K, k_lo + OG);
-        if (k_lo < k_hi) accumulate_offsets<NBT, ALIGNED, true>(p, nullptr, k_lo, k_hi, 0, my_row, q, nb0, acc);
+        // K = 1 (1x1 projections of the wide levels): accumulate_k1
+        if (p.K == 1 && (p.k1_path & 2)) { if (k_lo < k_hi) accumulate_k1<NBT, ALIGNED, true>(p, nullptr, my_row, q, nb0, acc); }
+        else if (k_lo < k_hi) accumulate_offsets<NBT, ALIGNED, true>(p, nullptr, k_lo, k_hi, 0, my_row, q, nb0, acc);
         if (tt > 0) __syncthreads();          // wave 0 is done with the previous tile's partials
         if (wave_id() > 0) {
 #pragma unroll
@@ -2359,6 +2443,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     __syncthreads();
 
     const int cbase = blockIdx.z * NCH * 16;  // first input channel of this workgroup
+    const int col0 = blockIdx.y * NBT * 16;   // first output column (round 5: layers beyond 64 output channels in slices of NBT blocks)
     f32x4 sc[NCH], sh[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
@@ -2379,7 +2464,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
             for (int nb = 0; nb < NBT; nb++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int ci = cbase + 16 * ch + 4 * q + r, j = 16 * nb + cl;
+                    const int ci = cbase + 16 * ch + 4 * q + r, j = col0 + 16 * nb + cl;
                     if (ci < p.Cin && j < p.Cout) slab[((size_t)k * p.Cin + ci) * p.Cout + j] = acc[ch * NBT + nb][r];
                 }
     };
@@ -2412,7 +2497,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
                     ga[t][ch] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)e[t].x * p.Cin + min(cbase + 16 * ch, p.Cin - 16) + 4 * q);
 #pragma unroll
                 for (int nb = 0; nb < NBT; nb++)
-                    gb[t][nb] = *reinterpret_cast<const f32x4 *>(p.dout + (size_t)e[t].y * p.Cout + 16 * nb + 4 * q);
+                    gb[t][nb] = *reinterpret_cast<const f32x4 *>(p.dout + (size_t)e[t].y * p.Cout + min(col0 + 16 * nb, p.Cout - 16) + 4 * q);
             }
         };
         load_entries(p_begin);
@@ -2511,7 +2596,7 @@ int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t strea
     const size_t per_wave = ((size_t)WGRAD_TB * (NCH + NBT) + 2 * NCH * NBT) * 256 * sizeof(float);
     int nw = (int)(LDS_BUDGET / per_wave);
     if (nw > 16) nw = 16;
-    dim3 grid(nblk_rows, 1, ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
+    dim3 grid(nblk_rows, ms3d_divup(p.NBtot, NBT), ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
     const size_t lds = (size_t)nw * per_wave;
     static const hipError_t attr = raise_lds_ceiling((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>);
     MS3D_CHECK(attr);
@@ -3251,6 +3336,8 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     p.out_stats = (out_stats && bn_partial && !bn_x) ? 1 : 0;
     static const int dyn_picks = [] { const char *e = getenv("MS3D_PL_DYNAMIC"); return e ? atoi(e) : 0; }();
     p.dyn_picks = dyn_picks;
+    static const int k1_path = [] { const char *e = getenv("MS3D_K1_PATH"); return e ? atoi(e) : 3; }();
+    p.k1_path = k1_path;
     p.in = in; p.wf = wf; p.nbr = nbr; p.out = out; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
@@ -3360,6 +3447,16 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     return MS3D_E_UNSUPPORTED;
 }
 
+// column blocks the offset-list backward-weight kernel serves: up to 4 (one slice); the K = 8 layers (strided / transposed
+// convolutions between the levels) up to 14 in slices on grid.y -- their alternative is the f32 table walk, which visits
+// every table entry of a 1-in-8 table (128 -> 96 at 51k rows: 234 us, 0.03 of the roofline); the K = 27 layers beyond 64
+// channels keep the bf16x3 kernel.  MS3D_WGRAD_LIST_K8=0: the table walk as before.
+static bool wgrad_list_cols_ok(int K, int nb)
+{
+    static const bool k8 = [] { const char *e = getenv("MS3D_WGRAD_LIST_K8"); return !e || atoi(e) != 0; }();
+    return nb <= 4 || (k8 && K == 8 && nb <= 14);
+}
+
 static bool wgrad_bf3_ok(int Vout, int K, int Cin, int Cout, bool use_list)
 {
     // below ~30 M row x channel x channel products the operand pass and the coarser row chunks cost more than the shorter
@@ -3379,7 +3476,7 @@ int ms3d_spconv_wgrad_is_bf16x3(int Vout, int K, int Cin, int Cout, int offset_l
 // to a batched launch (offset_list: an offset list of the table is passed)
 int ms3d_spconv_wgrad_is_table_walk(int Vout, int K, int Cin, int Cout, int offset_list)
 {
-    const bool use_list = offset_list && ms3d_divup(Cout, 16) <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
+    const bool use_list = offset_list && wgrad_list_cols_ok(K, ms3d_divup(Cout, 16)) && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     return (Vout > 0 && !use_list && !wgrad_bf3_ok(Vout, K, Cin, Cout, use_list) && ms3d_divup(Cout, 16) <= 14) ? 1 : 0;
 }
 // K = 1 with a small weight (the per-point Linear layers of the heads: 575k rows x 16 -> 16 / 20 / 3): the table walk's
@@ -3460,7 +3557,7 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
     static const int xwide_chunks = [] { const char *e = getenv("MS3D_WGRAD_XWIDE_CHUNKS"); return e ? atoi(e) : 128; }();
     if (n >= 100000 && chunks > wide_chunks) chunks = wide_chunks;
     if (n >= 400000 && chunks > xwide_chunks) chunks = xwide_chunks;
-    const bool use_list = ol_kt_start && ol_entries && p.NBtot <= 4 && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
+    const bool use_list = ol_kt_start && ol_entries && wgrad_list_cols_ok(K, p.NBtot) && K <= 27 && Cin % 16 == 0 && Cout % 16 == 0;
     p.ol_kt_start = ol_kt_start; p.ol_entries = ol_entries;
     int nblk;
     // offset-list kernel at 48 / 64 input channels: 64 parts x 3-4 input chunks is one workgroup per CU, and half the slabs
@@ -3498,11 +3595,13 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
     int rc;
     if (use_list) {
         // two input chunks per workgroup when Cin allows (entries and dout rows fetched once for both)
-        const bool two = ms3d_divup(Cin, 16) % 2 == 0 && nb <= 2;
-        rc = nb == 1 ? (two ? launch_wgrad_offsetlist<1, 2>(p, nblk, stream) : launch_wgrad_offsetlist<1, 1>(p, nblk, stream))
-           : nb == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
-           : nb == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
-                     : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
+        // more than four column blocks (K = 8 layers of the wide levels, round 5): two or more slices of <= 4 blocks on grid.y
+        const int nbs = nb <= 4 ? nb : ms3d_divup(nb, ms3d_divup(nb, 4));
+        const bool two = ms3d_divup(Cin, 16) % 2 == 0 && nbs <= 2;
+        rc = nbs == 1 ? (two ? launch_wgrad_offsetlist<1, 2>(p, nblk, stream) : launch_wgrad_offsetlist<1, 1>(p, nblk, stream))
+           : nbs == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
+           : nbs == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
+                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
         if (rc) return rc;
         if (defer_nblk) { *defer_nblk = nblk; return 0; }
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
