@@ -2,8 +2,8 @@
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1; export TMPDIR=/tmp
 TAG=$1; C=$2
 for M in pointgroup hais softgroup; do
-  bash tools/scripts/pmc_traffic.sh $M $C > /dev/null 2>&1
-  cp gpurun_out/r04_traffic_$M.json profiles/ 2>/dev/null   # bench.py reads roofline.traffic from there (this box only)
+  bash tools/scripts/pmc_traffic.sh $M $C $TAG > /dev/null 2>&1
+  cp gpurun_out/${TAG}_traffic_$M.json profiles/ 2>/dev/null   # bench.py reads roofline.traffic from there (this box only)
 done
 # the headline line three times (a shared host makes single runs jump by +-8 %): all three are kept, the one with the
 # median value is THE line
