@@ -100,6 +100,18 @@ def wgrad_stream(device):
     return s
 
 
+_HEADS = {}
+
+
+def heads_stream(device):
+    """the stream the per-point heads (forward, losses, early backward) run on beside the grouping window
+    (GeneralModel, MS3D_EARLY_HEADS=2)"""
+    s = _HEADS.get(device)
+    if s is None:
+        s = _HEADS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def side_stream(device):
     s = _SIDE.get(device)
     if s is None:

@@ -36,6 +36,12 @@ class _HandOverGradsFn(torch.autograd.Function):
         n = len(pack["grads"])
         if all(g is None for g in gs):
             return (None,) * (1 + n)
+        if pack.get("done") is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pack["done"])            # the early pass ran on the heads' own stream
+            for g in pack["grads"]:
+                if g is not None:
+                    g.record_stream(cur)
         same = all(g is not None and g.numel() == 1 and g.data_ptr() == gs[0].data_ptr() for g in gs)
         if same and pack["grads"] is not None:
             s = gs[0].reshape(())
@@ -106,9 +112,24 @@ class GeneralModel(nn.Module):
         GPU -- instead of after the ScoreNet, where the GPU has run dry at the grouping's last host round trip and waits
         for every launch.  `_loss` picks the result up."""
         if torch.is_grad_enabled() and "sem_labels" in data_dict and "instance_center_xyz" in data_dict:
+            side = output_dict.get("_heads_stream")
+            if side is not None:
+                # MS3D_EARLY_HEADS=2: the heads ran on their own stream (Backbone.forward); the losses and the heads'
+                # backward follow them there, NOW -- the host is milliseconds ahead of the GPU at this point, and the
+                # kernels run beside the grouping window's latency-bound chains instead of inside the GPU-bound backward pass
+                with torch.cuda.stream(side):
+                    output_dict["_point_losses"] = self._point_losses(data_dict, output_dict)
+                    self._early_point_backward(data_dict, output_dict, force=True)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                output_dict["_heads_done"] = done
+                pack = output_dict.get("_heads_pack")
+                if pack is not None:
+                    pack["done"] = done
+                return
             output_dict["_point_losses"] = self._point_losses(data_dict, output_dict)
 
-    def _early_point_backward(self, data_dict, output_dict):
+    def _early_point_backward(self, data_dict, output_dict, force=False):
         """Scheduling only (round 5): the backward of the per-point heads and losses -- ~1.2 ms of bandwidth-bound kernels
         over all points that nothing in the grouping / proposal branch feeds -- is queued HERE, right behind the grouping's
         last host round trip, where the GPU has run dry and idles ~1.7 ms while the interpreter issues the proposal
@@ -123,7 +144,7 @@ class GeneralModel(nn.Module):
         losses = output_dict.get("_point_losses")
         pf = output_dict.get("point_features")
         if (losses is None or pf is None or not pf.requires_grad or not torch.is_grad_enabled()
-                or os.environ.get("MS3D_EARLY_HEADS", "0") != "1"):
+                or "_heads_pack" in output_dict or not (force or os.environ.get("MS3D_EARLY_HEADS", "0") == "1")):
             return
         keys, vals = list(losses.keys()), list(losses.values())
         if any(v.grad_fn is None for v in vals):
@@ -137,12 +158,19 @@ class GeneralModel(nn.Module):
         for v in vals[1:]:
             total = total + v
         grads = torch.autograd.grad(total, inputs, retain_graph=True, allow_unused=True)
-        pack = {"losses": vals, "grads": grads, "inputs": inputs,
+        pack = {"losses": vals, "grads": grads, "inputs": inputs, "done": None,
                 "recompute": lambda d=data_dict, o=output_dict: self._point_losses(d, o)}
+        output_dict["_heads_pack"] = pack
         output_dict["_point_losses"] = dict(zip(keys, _HandOverGradsFn.apply(pack, *inputs)))
 
     def _loss(self, data_dict, output_dict):
         queued = output_dict.pop("_point_losses", None)
+        done = output_dict.pop("_heads_done", None)
+        if done is not None and queued is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)                     # the loss values were computed on the heads' stream
+            for v in queued.values():
+                v.record_stream(cur)
         return queued if queued is not None else self._point_losses(data_dict, output_dict)
 
     def _point_losses(self, data_dict, output_dict):

@@ -1,6 +1,8 @@
 """Networks assembled from the U-Net blocks: the `Backbone` (sparse U-Net + semantic / offset heads over points;
 reference minsu3d/model/module/backbone.py:8-43) and the `TinyUnet` that refines voxelised proposals (reference
 minsu3d/model/module/tiny_unet.py:7-19).  Sub-module names follow the reference so checkpoints keep their keys."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -74,6 +76,25 @@ class Backbone(nn.Module):
         x = ME.SparseTensor(features=voxel_features, coordinates=voxel_coordinates)
         x.coordinate_manager.prepare(self.n_levels)
         point_features = ME.gather_rows(self.unet(x).features, v2p_map)   # voxel -> point broadcast
+        if (point_features.is_cuda and torch.is_grad_enabled() and point_features.requires_grad and self.training
+                and os.environ.get("MS3D_EARLY_HEADS", "0") == "2"):
+            # Scheduling only (GeneralModel._early_point_backward, mode 2): the two heads run on their own stream; the
+            # caller's stream waits for their FORWARD (it needs the scores / offsets), while the losses and the heads'
+            # backward -- queued on that stream right behind -- run beside the grouping window
+            from ...backend import heads_stream
+            main, side = torch.cuda.current_stream(), heads_stream(point_features.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                sem = self.semantic_branch(point_features)
+                off = self.offset_branch(point_features)
+                done = torch.cuda.Event()
+                done.record(side)
+            point_features.record_stream(side)
+            main.wait_event(done)
+            sem.record_stream(main); off.record_stream(main)
+            return {"point_features": point_features, "semantic_scores": sem, "point_offsets": off, "_heads_stream": side}
         return {"point_features": point_features,
                 "semantic_scores": self.semantic_branch(point_features),
                 "point_offsets": self.offset_branch(point_features)}

@@ -528,3 +528,40 @@ def test_fused_residual_blocks_give_the_same_step(monkeypatch):
     m(b)
     h.remove()
     assert seen and len(calls) - n0 == n_blocks - 1
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_early_head_backward_modes_give_the_same_step(monkeypatch, mode):
+    """MS3D_EARLY_HEADS (scheduling only: 1 = the heads' backward queued behind the grouping, 2 = heads, losses and their
+    backward on their own stream beside the grouping window) against the ordinary step on the device: identical proposals
+    and losses, the heads' own gradients bit for bit, everything below them to the rounding of one reordered addition
+    (d point_features = ScoreNet part + heads part, summed in the other order); repeated, the step gives the same bytes"""
+    from minsu3d_amd import backend
+    from minsu3d_amd.backend import HipBackend
+    backend.set_backend(HipBackend())
+    u = tuple(t.cuda() for t in (torch.tensor([0.3, 0.6, 0.9]), torch.tensor([0.1, 0.2, 0.3])))
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((51, 52)).items()}
+    base = build_model(seed=11)
+
+    def step(env):
+        monkeypatch.setenv("MS3D_EARLY_HEADS", env)
+        m = copy.deepcopy(base).cuda()
+        m.voxelization_rand = u
+        m.train()
+        out = m(b)
+        losses = m._loss(b, out)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        return (out["proposal_scores"][1].clone(), {k: float(v.detach()) for k, v in losses.items()},
+                {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+
+    p0, l0, g0 = step("0")
+    p1, l1, g1 = step(mode)
+    p2, l2, g2 = step(mode)
+    assert torch.equal(p0, p1) and l0 == l1 and g0.keys() == g1.keys()
+    for n in g0:
+        if "semantic_branch" in n or "offset_branch" in n:
+            assert torch.equal(g0[n], g1[n]), n
+        else:
+            assert (g0[n] - g1[n]).abs().max().item() <= 1e-5 * g0[n].abs().max().item() + 1e-12, n
+        assert torch.equal(g1[n], g2[n]), n

@@ -1,0 +1,52 @@
+"""Host time of the pieces of the proposal branch (the host-bound stretch of a step between the grouping's last round
+trip and the backward pass): wall time per call inside bench.py's training loop, and a cProfile of the stretch.
+usage: python tools/scorenet_host.py [--model pointgroup]"""
+import sys, os, time, argparse, cProfile, pstats, io, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from minsu3d_amd.config import load_config
+from minsu3d_amd.model import general_model as gm, pointgroup as pgm
+from minsu3d_amd.common_ops.functions import common_ops
+import minsu3d_amd.MinkowskiEngine as ME
+
+ap = argparse.ArgumentParser(); ap.add_argument("--model", default="pointgroup"); args = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = load_config([f"model={args.model}", "data=scannetv2"])
+model = bench.build(cfg, dev); opt = model.configure_optimizers()
+batches = [bench.make_batch([4 * i + j for j in range(4)], dev) for i in range(3)]
+acc = {}
+prof = cProfile.Profile()
+state = {"on": False}
+
+
+def timed(name, fn, profile=False):
+    def w(*a, **k):
+        t0 = time.perf_counter()
+        if profile and state["on"]:
+            prof.enable()
+        try:
+            return fn(*a, **k)
+        finally:
+            if profile and state["on"]:
+                prof.disable()
+            acc.setdefault(name, []).append(time.perf_counter() - t0)
+    return w
+
+
+pgm.clusters_voxelization = timed("clusters_voxelization", pgm.clusters_voxelization, True)
+model.score_net.forward = timed("score_net.forward", model.score_net.forward, True)
+common_ops.roipool = timed("roipool", common_ops.roipool, True)
+real_loss = model._loss
+model._loss = timed("_loss", real_loss, True)
+ME_gather = ME.gather_rows
+pgm.ME.gather_rows = timed("gather_rows(p2v)", ME_gather, True)
+for i in range(6):
+    bench.train_step(model, model, opt, batches[i % 3], batches[(i + 1) % 3])
+torch.cuda.synchronize(); acc.clear(); state["on"] = True
+N = 20
+for i in range(N):
+    bench.train_step(model, model, opt, batches[i % 3], batches[(i + 1) % 3])
+torch.cuda.synchronize()
+for k, v in acc.items():
+    print(f"{k:28s} {1e3 * sum(v) / N:7.3f} ms/step ({len(v) // N} calls)")
+s = io.StringIO(); pstats.Stats(prof, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
