@@ -1348,24 +1348,61 @@ __global__ __launch_bounds__(256) void dir_claim_kernel(
         }
     }
     const int waves = blockDim.x >> 6, l = lane_id();
-    for (int p = blockIdx.x * waves + wave_id(); p < nF; p += gridDim.x * waves) {
-        const int node = F[p];
-        const int r = root[node];
+    // the wave's frontier nodes through a three-stage software pipeline (round 5, as glob_mark_bm_kernel: node A's claims are
+    // posted while node B's first slices, node C's header / root / label and node D's id are in flight)
+    const int stride = gridDim.x * waves;
+    struct Hdr { int node, st, ln, r, lab; };
+    auto load_id = [&](int p) { return p < nF ? F[p] : -1; };
+    auto load_hdr = [&](int node) {
+        Hdr h{node, 0, 0, 0, 0};
+        if (node >= 0) {
+            h.st = start_len[node * 2]; h.ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);   // canonical lists: <= 1000
+            h.r = root[node];
+            h.lab = thr.mode == 0 ? (int)sem[node] : 0;
+        }
+        return h;
+    };
+    struct Body { int j[4], base, done, seg; };
+    auto load_body = [&](const Hdr &h) {
+        Body b;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = 64 * u + l;
+            b.j[u] = (h.node >= 0 && t < h.ln) ? ball_idx[h.st + t] : -1;
+        }
+        b.base = b.done = b.seg = 0;
+        if (h.node >= 0) { b.base = comp_base[h.r]; b.done = done_cur[h.r]; b.seg = seg_start_cur[h.r]; }
+        return b;
+    };
+    int p = blockIdx.x * waves + wave_id();
+    Hdr hA = load_hdr(load_id(p)), hB = load_hdr(load_id(p + stride));
+    int idC = load_id(p + 2 * stride);
+    Body bA = load_body(hA);
+    for (; p < nF; p += stride) {
+        const int idD = load_id(p + 3 * stride);
+        const Hdr hC = load_hdr(idC);
+        const Body bB = load_body(hB);
+        const int node = hA.node, r = hA.r;
         if (l == 0) {
-            const int qpos = comp_base[r] + done_cur[r] + (p - seg_start_cur[r]);
+            const int qpos = bA.base + bA.done + (p - bA.seg);
             scratch_node[qpos] = node;
             scratch_seed[qpos] = r;
         }
-        const int st = start_len[node * 2], ln = min(start_len[node * 2 + 1], 64 * MAX_SLICES);  // canonical lists: <= 1000
-        const int lab = thr.mode == 0 ? (int)sem[node] : 0;
+        const int st = hA.st, ln = hA.ln;
+        const int lab = hA.lab;
         unsigned long long *am = amask + mask_slot(st, node, strict);
         // four 64-edge slices per trip: the four index loads, then the four claim gathers are in flight together
         for (int t0 = 0; t0 < ln; t0 += 256) {
             int j[4], c[4];
+            if (t0 == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = t0 + 64 * u + l;
-                j[u] = t < ln ? ball_idx[st + t] : -1;
+                for (int u = 0; u < 4; u++) j[u] = bA.j[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u + l;
+                    j[u] = t < ln ? ball_idx[st + t] : -1;
+                }
             }
             int sj[4];
 #pragma unroll
@@ -1390,6 +1427,7 @@ __global__ __launch_bounds__(256) void dir_claim_kernel(
                 if (l == 0) am[(t0 >> 6) + u] = m;
             }
         }
+        hA = hB; bA = bB; hB = hC; idC = idD;
     }
 }
 
