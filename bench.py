@@ -93,9 +93,11 @@ def train_step(model, ddp, opt, batch, next_batch=None):
                                     channels=model.backbone.level_channels, point_map=next_batch["voxel_point_map"])
         if PREFETCH_AT == "grouping":
             model.schedule_after_backbone(prefetch)
+        elif PREFETCH_AT == "proposals":
+            model.schedule_after_grouping(prefetch)
     out = ddp(batch)
     loss = sum(model._loss(batch, out).values())
-    if prefetch is not None and PREFETCH_AT != "grouping":
+    if prefetch is not None and PREFETCH_AT not in ("grouping", "proposals"):
         prefetch()
     loss.backward()
     opt.step()

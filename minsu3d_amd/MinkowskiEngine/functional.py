@@ -424,7 +424,9 @@ class PermuteRowsFn(torch.autograd.Function):
 
 def gather_rows(x, idx, max_dup=None):
     """differentiable x[idx] for 2-D float features and an int64 row index.  max_dup: the caller's bound on how many
-    entries of idx name the same row (<= 2: the backward's float atomics are order-independent, no sort needed)"""
+    NON-ZERO addends one element of the gradient can collect -- how many entries of idx name the same row, or fewer when
+    the caller knows the incoming gradient is sparse (<= 2: the backward's float atomics are order-independent -- a + b =
+    b + a and adding zeros is exact -- no sort needed)"""
     if x.dim() == 2 and idx.dim() == 1 and idx.dtype == torch.int64 and x.requires_grad:
         return GatherRowsFn.apply(x, idx, max_dup)
     return _rows(x, idx) if x.dim() == 2 and idx.dim() == 1 else x[idx]

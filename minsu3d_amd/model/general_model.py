@@ -106,6 +106,17 @@ class GeneralModel(nn.Module):
         the GPU-bound backward pass (VERDICT r3 #6).  MS3D_PREFETCH_AT=backward restores the old placement."""
         self.__dict__["_after_backbone"] = fn
 
+    def schedule_after_grouping(self, fn):
+        """Scheduling only: run `fn()` once, in the next forward, right behind the grouping's last host round trip (the
+        models call `_after_grouping()` in front of the proposal voxelisation) -- the stretch where the GPU has run dry and
+        waits for the interpreter.  MS3D_PREFETCH_AT=proposals puts the next batch's coordinate prefetch there."""
+        self.__dict__["_after_grouping_fn"] = fn
+
+    def _after_grouping(self):
+        fn = self.__dict__.pop("_after_grouping_fn", None)
+        if fn is not None:
+            fn()
+
     def _queue_point_losses(self, data_dict, output_dict):
         """Scheduling only: the per-point losses need nothing but the backbone's outputs, so the grouping models put their
         ~30 small launches on the stream right after the backbone -- where the interpreter is milliseconds ahead of the
@@ -141,6 +152,7 @@ class GeneralModel(nn.Module):
         heads' backward is ~0.6 ms of kernels issued through ~80 autograd nodes, i.e. ~0.7 ms of interpreter time that moves
         from the GPU-bound backward pass (where the host is milliseconds ahead) into this host-bound stretch -- the step
         stays at 20.0 ms either way.  Kept as a tested option for a host whose launch path is cheaper."""
+        self._after_grouping()
         losses = output_dict.get("_point_losses")
         pf = output_dict.get("point_features")
         if (losses is None or pf is None or not pf.requires_grad or not torch.is_grad_enabled()

@@ -98,7 +98,10 @@ class PointGroup(GeneralModel):
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"],
                                          data_dict["point_xyz"], net.score_scale, net.score_fullscale, self.device,
                                          rand=self.voxelization_rand, max_dup=2)   # a point: <= one cluster per grouping
-        score_feats = ME.gather_rows(self.score_net(vox).features, p2v)      # (sumNPoint, m)
+        # (max_dup: the gradient that comes back over this gather is roipool's -- ONE non-zero entry per proposal and channel,
+        # a proposal's points only name that proposal's voxels -- so no element of the voxel gradient collects more than one
+        # non-zero addend: the one-launch scatter-add is order-independent here, no sorted index is needed)
+        score_feats = ME.gather_rows(self.score_net(vox).features, p2v, max_dup=1)      # (sumNPoint, m)
         pooled = common_ops.roipool(score_feats, proposals_offset)            # (nProposal, m)
         out["proposal_scores"] = (self.score_branch(pooled), proposals_idx, proposals_offset)
         return out

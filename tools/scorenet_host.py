@@ -33,6 +33,13 @@ def timed(name, fn, profile=False):
     return w
 
 
+from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
+from minsu3d_amd.model.module import common as cm_mod
+CoordinateManager.prepare = timed("  CoordinateManager.prepare", CoordinateManager.prepare)
+be = __import__("minsu3d_amd.backend", fromlist=["x"]).get_backend()
+for name in ("pairlist", "offsetlist", "downsample", "kmap_k3", "kmap_k2", "sparse_quantize", "proposal_voxel_coords"):
+    pass
+cm_mod.ResidualBlock.forward = timed("  ResidualBlock.forward (all)", cm_mod.ResidualBlock.forward)
 pgm.clusters_voxelization = timed("clusters_voxelization", pgm.clusters_voxelization, True)
 model.score_net.forward = timed("score_net.forward", model.score_net.forward, True)
 common_ops.roipool = timed("roipool", common_ops.roipool, True)
