@@ -391,10 +391,14 @@ class GatherRowsFn(torch.autograd.Function):
             # the backward sums in a fixed order over a stable sort of idx: take the one the loader's prefetch left on the
             # tensor, or queue it now on the helper thread / side stream
             cached = getattr(idx, "_ms3d_sorted", None)
+            queued = getattr(idx, "_ms3d_presort", None)
             if cached is not None and cached[2] == idx._version:
                 ctx.sorted = cached[:2]
+            elif queued is not None and queued[1] == idx._version:
+                ctx.sorted = queued[0]            # a second gather over the same index (HAIS: features and mask scores)
             elif idx.numel() >= GatherRowsFn.PRESORT_MIN_ROWS:
                 ctx.sorted = be.presort_rows(idx)
+                idx._ms3d_presort = (ctx.sorted, idx._version)
         return _rows(x, idx)
 
     @staticmethod

@@ -4,6 +4,7 @@ per-point mask branch + RoI-pooled score branch.  The grouping stays on the devi
 import torch
 import torch.nn as nn
 
+from .. import MinkowskiEngine as ME
 from ..common_ops.functions import common_ops, hais_ops
 from .general_model import GeneralModel, clusters_voxelization, get_segmented_scores, scene_offsets
 from .module import TinyUnet
@@ -57,8 +58,10 @@ class HAIS(GeneralModel):
                                          net.score_scale, net.score_fullscale, self.device, rand=self.voxelization_rand,
                                          max_dup=1)                 # a point belongs to at most one aggregated cluster
         inst = self.tiny_unet(vox)
-        score_feats = inst.features[p2v]
-        mask_scores = self.mask_branch(inst.features)[p2v]        # linear on voxels first, then voxel -> point
+        # (two gathers over ONE index: the engine's row gather, whose backward sums in a fixed order over a sort of p2v that is
+        # queued once, now, off the critical path -- torch's indexing would sort the index again inside each backward)
+        score_feats = ME.gather_rows(inst.features, p2v)
+        mask_scores = ME.gather_rows(self.mask_branch(inst.features), p2v)   # linear on voxels first, then voxel -> point
         if self.current_epoch > net.use_mask_filter_score_feature_start_epoch:
             keep = (torch.sigmoid(mask_scores) >= net.mask_filter_score_feature_thre).to(score_feats.dtype)
             score_feats = score_feats * keep

@@ -4,6 +4,7 @@ TinyUnet refinement with classification / mask-scoring / IoU heads and a global 
 import torch
 import torch.nn as nn
 
+from .. import MinkowskiEngine as ME
 from ..common_ops.functions import common_ops, softgroup_ops
 from .general_model import GeneralModel, clusters_voxelization, scene_offsets
 from .module import TinyUnet
@@ -70,13 +71,21 @@ class SoftGroup(GeneralModel):
         net = cfg.model.network
         dev = sem_scores.device
         C_ = cfg.data.classes
-        B = int(data_dict["vert_batch_ids"].max().item()) + 1 if data_dict["vert_batch_ids"].numel() else 1
-        if C_ * B > 255:                                  # group ids are uint8 like the reference's batch ids
-            return self._soft_grouping_loop(data_dict, sem_scores, offsets)
         mask = sem_scores > net.grouping_cfg.score_thr                      # [N, C]
         for cls in cfg.data.ignore_classes:
             mask[:, cls - 1] = False
         mask &= (mask.sum(0) >= net.test_cfg.min_npoint)[None, :]           # classes with too few points are skipped
+        # one host round trip for two numbers: the scene count, and in how many classes' candidate sets a point sits at most
+        # (= the most proposals one point can be a member of: the member gather's backward then knows whether its float
+        # atomics are order-independent -- at most two addends per row -- or a sorted index is needed)
+        if data_dict["vert_batch_ids"].numel():
+            two = torch.stack((data_dict["vert_batch_ids"].max().long(), mask.sum(1).max())).tolist()
+            B, self._max_member_dup = int(two[0]) + 1, int(two[1])
+        else:
+            B, self._max_member_dup = 1, 1
+        if C_ * B > 255:                                  # group ids are uint8 like the reference's batch ids
+            self._max_member_dup = None
+            return self._soft_grouping_loop(data_dict, sem_scores, offsets)
         cls_id, pt = mask.t().nonzero(as_tuple=True)                        # class-major, points ascending inside
         if pt.numel() == 0:
             return torch.zeros((0, 2), dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
@@ -113,9 +122,9 @@ class SoftGroup(GeneralModel):
         self._early_point_backward(data_dict, out)     # fills the GPU while the proposal branch is being issued
         vox, p2v = clusters_voxelization(proposals_idx, proposals_offset, out["point_features"], data_dict["point_xyz"],
                                          net.instance_voxel_cfg.scale, net.instance_voxel_cfg.spatial_shape, self.device,
-                                         rand=self.voxelization_rand)
+                                         rand=self.voxelization_rand, max_dup=getattr(self, "_max_member_dup", None))
         feats = self.tiny_unet(vox)
-        out["mask_scores"] = self.mask_scoring_branch(feats.features)[p2v]
+        out["mask_scores"] = ME.gather_rows(self.mask_scoring_branch(feats.features), p2v)   # (fixed-order backward, as HAIS)
         out["instance_batch_idxs"] = feats.coordinates[:, 0][p2v]
         pooled = self.global_pool(feats)
         out["cls_scores"] = self.classification_branch(pooled)
