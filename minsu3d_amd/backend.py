@@ -401,6 +401,7 @@ class HipBackend:
         def job():
             with torch.cuda.stream(side), torch.no_grad():
                 side.wait_event(ready)
+                idx.record_stream(side)      # the sort may still be reading it when the last reference on the caller's side dies
                 keys, order = torch.sort(idx, stable=True)
                 done = torch.cuda.Event()
                 done.record(side)

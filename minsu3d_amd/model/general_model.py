@@ -32,7 +32,7 @@ class _HandOverGradsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        pack, ctx.pack = ctx.pack, None
+        pack = ctx.pack                      # (kept: a second backward pass over a retained graph hands the same gradients over)
         n = len(pack["grads"])
         if all(g is None for g in gs):
             return (None,) * (1 + n)
