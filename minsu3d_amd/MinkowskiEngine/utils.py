@@ -22,7 +22,13 @@ def sparse_quantize(coordinates, features=None, return_index=False, return_inver
     out = [c[uniq_l]]
     if features is not None:
         f = torch.from_numpy(features) if isinstance(features, np.ndarray) else features
-        out.append(f[uniq_l.to(f.device)])
+        if torch.is_tensor(f) and f.is_cuda and f.dim() == 2 and f.dtype == torch.float32 and f.requires_grad:
+            # the first-occurrence rows: a gather over UNIQUE indices -- the engine's row gather, whose backward is one
+            # scatter launch (no two sources per row: order-independent) where torch's indexing backward sorts the index
+            from . import functional as Fn
+            out.append(Fn.gather_rows(f, uniq_l, max_dup=1))
+        else:
+            out.append(f[uniq_l.to(f.device)])
     if return_index:
         out.append(uniq_l)
     if return_inverse:
