@@ -72,7 +72,8 @@ def test_pointgroup_step_hip_vs_oracle():
 
 
 def test_step_is_reproducible_on_device():
-    """same inputs twice -> identical proposals, losses equal to float-atomic noise"""
+    """same inputs twice (eval mode) -> identical proposals and scores; the TRAINING-mode version of this check, byte for byte
+    over losses, gradients and statistics, is tests/test_determinism_gpu.py"""
     from minsu3d_amd import backend
     from minsu3d_amd.backend import HipBackend
     backend.set_backend(HipBackend())
@@ -163,7 +164,7 @@ def test_weight_images_one_launch_equals_per_layer_and_tracks_updates(monkeypatc
         monkeypatch.setenv("MS3D_WEIGHT_MULTI", "1" if multi else "0")
         m = build_model(seed=3).cuda()
         m.voxelization_rand = u
-        m.eval()                       # fixed BN statistics: no float-atomic noise between the two runs
+        m.eval()                       # fixed BN statistics
         opt = torch.optim.SGD(m.parameters(), lr=5e-2)   # (Adam would turn last-bit gradient noise into +-lr steps)
         losses = []
         for _ in range(2):
@@ -180,7 +181,7 @@ def test_weight_images_one_launch_equals_per_layer_and_tracks_updates(monkeypatc
     assert not any(hasattr(p, "_ms3d_wf") for p in m0.parameters())
     assert l1[0] == l0[0] and abs(l1[1] - l0[1]) < 1e-5 * abs(l0[1]) and abs(l1[0] - l1[1]) > 1e-3 * abs(l1[0])
     for (n, p), (_, q) in zip(m1.named_parameters(), m0.named_parameters()):
-        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n     # scatter-add atomics in the backward: last-bit noise
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n
     # outside the model's forward the stamp is void: a changed weight is re-laid by the convolution itself
     monkeypatch.setenv("MS3D_WEIGHT_MULTI", "1")
     conv = next(mod for mod in m1.modules() if isinstance(mod, ME.MinkowskiConvolution) and mod.kernel_size == 3
@@ -359,8 +360,8 @@ def test_point_batchnorm_relu_matches_torch(C_):
 def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
     """MS3D_WGRAD_STREAM: the backward-weight kernels of every layer on a second stream beside the backward-data chain
     (joined per layer = 1, or once at the end of the backward pass = 2) against the single-stream order: the same
-    kernels on the same data, so every gradient agrees to the float-atomic noise of the point <-> voxel scatter-adds
-    (a missing join would show as garbage), also when the step is repeated back to back"""
+    kernels on the same data, so every gradient agrees (a missing join would show as garbage), also when the step is
+    repeated back to back"""
     from minsu3d_amd import backend
     from minsu3d_amd.backend import HipBackend
     be = HipBackend()
@@ -369,7 +370,7 @@ def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
     b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in small_batch((21, 22)).items()}
     m = build_model(seed=5).cuda()
     m.voxelization_rand = u
-    m.eval()                      # fixed BatchNorm statistics: no float-atomic noise between the runs
+    m.eval()                      # fixed BatchNorm statistics
     grads = {}
     try:
         for mode in (0, 1, 2, 2):
@@ -392,7 +393,7 @@ def test_deferred_slab_reduction_gives_the_same_gradients(monkeypatch):
     """The backward-weight slab reductions of a group of layers run as ONE launch when the group's last layer is done
     (modules.prepare_conv_weights -> functional.GroupFlushFn -> backend.WgradQueue) instead of one launch per layer:
     same kernels' slabs, same per-element summation order.  Whole-model gradients with and without the deferral
-    (eval-mode statistics: no float-atomic noise in the BatchNorms), flush count = layer groups, every convolution's
+    (eval-mode statistics), flush count = layer groups, every convolution's
     reduction accounted for; with an existing .grad (accumulation) the sum is right too."""
     from minsu3d_amd import backend
     from minsu3d_amd.backend import HipBackend, WgradQueue

@@ -539,7 +539,7 @@ def test_batchnorm_after_cat_takes_the_parts_statistics(be):
 def test_host_extension_and_ctypes_paths_agree(be, oracle, cin, cout, K):
     """the per-layer calls through the PyTorch C++ extension (minsu3d_amd/lib/_ms3d_host.so, csrc_host/ms3d_host.cpp)
     and through ctypes enter the same C ABI with the same arguments: bit-identical outputs, forward and backward, with
-    and without the deferred slab reduction (the statistics side outputs to float-atomic noise); the extension is what a
+    and without the deferred slab reduction; the extension is what a
     default backend uses"""
     from minsu3d_amd.backend import HipBackend, WgradQueue
     assert be.ext is not None and be.ext.__file__.endswith("_ms3d_host.so")
@@ -573,10 +573,9 @@ def test_host_extension_and_ctypes_paths_agree(be, oracle, cin, cout, K):
         fin = b_.bn_finalize(stats, vout, 1e-5, 0.1, pre[0], pre[1], None, None)
         outs.append([y, stats, dx, dgb, dW, dx2, dW2, torch.stack(fin), b_.gather_rows(y, torch.arange(0, vout, 3, device="cuda"))])
     for i, (a, b2) in enumerate(zip(*outs)):
-        if i in (1, 2, 3, 7):   # per-channel sums collected with LDS float atomics (and the dx built from them): run-to-run noise
-            assert torch.allclose(a, b2, rtol=1e-4, atol=1e-4 * float(b2.abs().max()))
-        else:
-            assert torch.equal(a, b2), i
+        # (rounds 1-4: the statistics side outputs and the dx built from them carried the run-to-run noise of LDS float atomics
+        # and were compared to 1e-4; every sum has a fixed order since round 5)
+        assert torch.equal(a, b2), i
 
 
 def test_batched_backward_weight_launch_is_bit_identical(be, oracle):
