@@ -35,13 +35,34 @@ def timed(name, fn, profile=False):
 
 from minsu3d_amd.MinkowskiEngine.tensor import CoordinateManager
 from minsu3d_amd.model.module import common as cm_mod
-CoordinateManager.prepare = timed("  CoordinateManager.prepare", CoordinateManager.prepare)
+
 be = __import__("minsu3d_amd.backend", fromlist=["x"]).get_backend()
 for name in ("pairlist", "offsetlist", "downsample", "kmap_k3", "kmap_k2", "sparse_quantize", "proposal_voxel_coords"):
     pass
-cm_mod.ResidualBlock.forward = timed("  ResidualBlock.forward (all)", cm_mod.ResidualBlock.forward)
+
 pgm.clusters_voxelization = timed("clusters_voxelization", pgm.clusters_voxelization, True)
-model.score_net.forward = timed("score_net.forward", model.score_net.forward, True)
+_sn = model.score_net
+
+
+def _sn_forward(x):
+    t0 = time.perf_counter(); x.coordinate_manager.prepare(2); t1 = time.perf_counter()
+    be_ = __import__("minsu3d_amd.backend", fromlist=["x"]).get_backend()
+    cm = x.coordinate_manager
+    for ts, c in ((1, 16), (2, 32)):      # the lists the convolutions will ask for (built lazily inside them otherwise)
+        nbr = cm.k3(ts); v = cm.size(ts)
+        be_.pairlist(nbr, 27, v, c, c); be_.offsetlist(nbr, 27, v)
+    down, up = cm.k2(1); vc = cm.size(2)
+    be_.pairlist(down, 8, vc, 16, 32); be_.offsetlist(down, 8, vc); be_.pairlist(up, 8, cm.size(1), 32, 16); be_.offsetlist(up, 8, cm.size(1))
+    t2 = time.perf_counter()
+    y = _sn.unet(x)
+    t3 = time.perf_counter()
+    acc.setdefault("  tiny: coordinate sets + kernel maps", []).append(t1 - t0)
+    acc.setdefault("  tiny: pair / offset lists", []).append(t2 - t1)
+    acc.setdefault("  tiny: unet modules", []).append(t3 - t2)
+    return y
+
+
+model.score_net.forward = timed("score_net.forward", _sn_forward, True)
 common_ops.roipool = timed("roipool", common_ops.roipool, True)
 real_loss = model._loss
 model._loss = timed("_loss", real_loss, True)
