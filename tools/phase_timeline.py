@@ -33,6 +33,18 @@ if score is not None:
     score.register_forward_hook(lambda m, a, o: mark("scorenet_end"))
 
 
+# the proposal branch starts at clusters_voxelization (right behind the grouping's last round trip)
+import importlib
+_mod = importlib.import_module(type(model).__module__)
+if hasattr(_mod, "clusters_voxelization"):
+    _cv = _mod.clusters_voxelization
+
+    def _cv_marked(*a, **k):
+        mark("proposals_begin")
+        return _cv(*a, **k)
+    _mod.clusters_voxelization = _cv_marked
+
+
 def step(b, nxt):
     mark("step_begin")
     opt.zero_grad(set_to_none=True)
