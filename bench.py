@@ -89,15 +89,19 @@ def train_step(model, ddp, opt, batch, next_batch=None):
     prefetch = None
     if next_batch is not None:
         def prefetch():
-            ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels, wait_current_stream=False,
+            # (_ev / bfs: the prefetch stream waits until the GPU -- not just the interpreter -- has reached this point)
+            ME.prefetch_coordinates(next_batch["voxel_xyz"], model.backbone.n_levels,
+                                    wait_current_stream=PREFETCH_AT in ("grouping_ev", "bfs"),
                                     channels=model.backbone.level_channels, point_map=next_batch["voxel_point_map"])
-        if PREFETCH_AT == "grouping":
+        if PREFETCH_AT in ("grouping", "grouping_ev"):
             model.schedule_after_backbone(prefetch)
+        elif PREFETCH_AT == "bfs" and hasattr(model, "schedule_after_ballquery"):
+            model.schedule_after_ballquery(prefetch)
         elif PREFETCH_AT == "proposals":
             model.schedule_after_grouping(prefetch)
     out = ddp(batch)
     loss = sum(model._loss(batch, out).values())
-    if prefetch is not None and PREFETCH_AT not in ("grouping", "proposals"):
+    if prefetch is not None and PREFETCH_AT not in ("grouping", "grouping_ev", "bfs", "proposals"):
         prefetch()
     loss.backward()
     opt.step()

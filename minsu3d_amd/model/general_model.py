@@ -112,6 +112,16 @@ class GeneralModel(nn.Module):
         waits for the interpreter.  MS3D_PREFETCH_AT=proposals puts the next batch's coordinate prefetch there."""
         self.__dict__["_after_grouping_fn"] = fn
 
+    def schedule_after_ballquery(self, fn):
+        """Scheduling only: run `fn()` once, in the next forward, right behind the (longer) grouping's ball query -- in
+        front of its BFS, a chain of small dependent launches that leaves most of the chip idle (MS3D_PREFETCH_AT=bfs)."""
+        self.__dict__["_after_ballquery_fn"] = fn
+
+    def _after_ballquery(self):
+        fn = self.__dict__.pop("_after_ballquery_fn", None)
+        if fn is not None:
+            fn()
+
     def _after_grouping(self):
         fn = self.__dict__.pop("_after_grouping_fn", None)
         if fn is not None:

@@ -22,9 +22,11 @@ class PointGroup(GeneralModel):
         self.score_branch = nn.Linear(m, 1)
         self.voxelization_rand = None   # tests inject the two uniform draws here
 
-    def _group(self, xyz, batch_idxs, batch_offsets, sem_fg, object_idxs, mean_active):
+    def _group(self, xyz, batch_idxs, batch_offsets, sem_fg, object_idxs, mean_active, hook=False):
         net = self.hparams.cfg.model.network.cluster
         idx, start_len = common_ops.ballquery_batch_p(xyz, batch_idxs, batch_offsets, net.cluster_radius, mean_active)
+        if hook:
+            self._after_ballquery()
         prop_idx, prop_off = pointgroup_ops.pg_bfs_cluster(sem_fg, idx, start_len, net.cluster_npoint_thre)
         prop_idx = prop_idx.long()
         prop_idx[:, 1] = object_idxs[prop_idx[:, 1]]          # foreground index -> global point index
@@ -74,7 +76,7 @@ class PointGroup(GeneralModel):
             pending = _worker().submit(second)
             try:
                 p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
-                                               net.cluster.cluster_shift_meanActive)
+                                               net.cluster.cluster_shift_meanActive, hook=True)
             finally:
                 p_orig, o_orig = pending.result()
                 main.wait_stream(side)
@@ -84,7 +86,7 @@ class PointGroup(GeneralModel):
             o_orig.record_stream(main)
         else:
             p_shift, o_shift = self._group(shifted, batch_idxs, batch_offsets, sem_fg, object_idxs,
-                                           net.cluster.cluster_shift_meanActive)
+                                           net.cluster.cluster_shift_meanActive, hook=True)
             p_orig, o_orig = self._group(xyz, batch_idxs, batch_offsets, sem_fg, object_idxs,
                                          net.cluster.cluster_meanActive)
         p_shift[:, 0] += o_orig.size(0) - 1                    # renumber the second proposal set after the first
