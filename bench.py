@@ -387,6 +387,8 @@ def main(argv=None):
     sync_all()
     dt = time.perf_counter() - t0
     step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    if os.environ.get("MS3D_STEP_DUMP") and rank == 0:
+        print("step_ms:", " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
