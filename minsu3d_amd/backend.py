@@ -624,6 +624,8 @@ class WgradQueue:
     _turn = 0
     RING = 16                           # pinned staging slots: a slot is rewritten 16 flushes (~4 steps) later
 
+    side_mode = False            # MS3D_WGRAD_STREAM=3: see flush()
+
     def __init__(self, lib, timer=None):
         self.lib = lib
         self.items = []          # (slabs tensor, dW tensor, n floats per slab, slabs)
@@ -644,6 +646,21 @@ class WgradQueue:
         shape class | reduction descriptions, 32 bytes each], then one launch per shape class and one reduction launch"""
         launches, self.launches = self.launches, []
         items, self.items = self.items, []
+        if self.side_mode:
+            # MS3D_WGRAD_STREAM=3: the group's backward-weight kernels ran on the second stream beside the backward-data
+            # chain; their slab reduction follows them THERE, and the caller's stream waits for that stream once per group
+            # -- here, in the group's GroupFlushFn node, i.e. in front of everything that reads a dW of the group (gradient
+            # accumulation, a data-parallel wrapper's bucket hooks, the optimizer).
+            dev_ = items[0][1].device if items else torch.device("cuda", torch.cuda.current_device())
+            main, side = torch.cuda.current_stream(dev_), wgrad_stream(dev_)
+            if items:
+                with torch.cuda.stream(side):
+                    self._flush(launches, items)
+            main.wait_stream(side)
+            return
+        self._flush(launches, items)
+
+    def _flush(self, launches, items):
         if not launches and not items:
             return
         dev = (launches[0][3][0] if launches else items[0][1]).device
@@ -979,8 +996,12 @@ class _HipEngine:
         its own stream: the flush would have to run there)"""
         on = self.__dict__.get("_wgrad_defer")
         if on is None:
-            on = self._wgrad_defer = os.environ.get("MS3D_WGRAD_DEFER", "1") != "0" and self.wgrad_stream_mode() == 0
-        return WgradQueue(self.lib, self.kernel_timer) if on else None
+            on = self._wgrad_defer = os.environ.get("MS3D_WGRAD_DEFER", "1") != "0" and self.wgrad_stream_mode() in (0, 3)
+        if not on:
+            return None
+        q = WgradQueue(self.lib, self.kernel_timer)
+        q.side_mode = self.wgrad_stream_mode() == 3     # the group's backward-weight work ran on the second stream
+        return q
 
     def wgrad_batch_enabled(self):
         """MS3D_WGRAD_BATCH (default 1): the backward-weight kernels of the small levels (f32 table walk) of a layer group run
@@ -1072,7 +1093,8 @@ class _HipEngine:
             # block goes back to the side stream's pool and is reused behind the kernels still writing it
             with torch.cuda.stream(side):
                 ws2 = self.ws.get("layer_wgrad", 4 * self._geom("ms3d_spconv_layer_ws_floats", vin, vout, K, cin, cout), dev)
-            defer = None
+            if mode != 3:
+                defer = None       # (mode 3 keeps the deferral: the group's flush runs on the second stream and joins there)
         slabs, n_defer = None, None
         if defer is not None:
             if "_defer_n" not in self.__dict__:
@@ -1088,7 +1110,7 @@ class _HipEngine:
             int(bool(has_bn and bn["relu"])), int(bool(has_bn and bn["training"])), int(bool(need_dx)), _p(dx),
             _p(_f32(dx_add) if (dx_add is not None and need_dx) else None), _p(dgb), _p(dW), _p(ws), _p(plf[0]), _p(plf[1]), _p(plb[0]),
             _p(plb[1]), ev0, ev1, ev2, ev3, _p(ws2), side.cuda_stream if side is not None else None,
-            int(mode == 1 or (mode == 2 and join_now)), _p(slabs), n_defer,
+            int(mode == 1 or (mode == 2 and join_now) or (mode == 3 and defer is None)), _p(slabs), n_defer,
             C.addressof(launch) if launch is not None else None, _lib.stream_handle()),
             "ms3d_spconv_layer_backward")
         if launch is not None and np.frombuffer(launch, dtype=np.int32, count=6)[4] != 0:
@@ -1101,6 +1123,12 @@ class _HipEngine:
             x.record_stream(side); dy.record_stream(side); dW.record_stream(side)
             if not join_now:
                 self._queue_wgrad_join(side)
+        elif mode == 3 and defer is not None:
+            # joined by the layer group's flush (WgradQueue.flush, behind which every consumer of dW sits): until then
+            # the second stream reads x / dy and writes the slabs / dW, all of them blocks of the caller's stream's pool
+            x.record_stream(side); dy.record_stream(side); dW.record_stream(side)
+            if slabs is not None:
+                slabs.record_stream(side)
         return (dx if need_dx else None), dgb, dW
 
     @staticmethod
@@ -1111,7 +1139,9 @@ class _HipEngine:
     def wgrad_stream_mode(self):
         """MS3D_WGRAD_STREAM: 0 (default) backward-weight on the caller's stream; 1: on a second stream, joined at the
         end of every layer's backward (safe under DistributedDataParallel, whose gradient hooks order only against the
-        caller's stream); 2: joined once, at the end of the backward pass (single process).
+        caller's stream); 2: joined once, at the end of the backward pass (single process); 3 (round 5): joined once
+        per layer GROUP, inside the group's deferred-reduction node (functional.GroupFlushFn) -- safe under
+        DistributedDataParallel like 1 (no gradient reaches a hook in front of the join), overlapping like 2.
         Measured (profiles/r03_wgrad_stream_sweep.txt, one MI355X, 40 steps): HAIS 81.5 -> 83.7 (mode 1) -> 85.0 scenes/s
         (mode 2); PointGroup unchanged within its run-to-run noise (169-175 in every mode).  The two streams' kernels
         slow each other down (summed kernel time of the backward pass 11.3 -> 15.2 ms on PointGroup for a span that

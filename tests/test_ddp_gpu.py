@@ -9,7 +9,7 @@ when a ReLU mask flipped between the two evaluations.  Round 5 made the step bit
   * completeness -- what DistributedDataParallel's bucket hooks all-reduced is the average of the ranks' COMPLETE local
     gradients, per parameter tensor, for every combination of the machinery that sits between a backward-weight kernel
     and the hook: fused block nodes on / off, deferred + batched slab reductions on / off, backward-weight on a second
-    stream (MS3D_WGRAD_STREAM=1).  A hook that fired before its layer group's flush would average unreduced slabs --
+    stream joined per layer (MS3D_WGRAD_STREAM=1) or per layer group inside the deferred-reduction node (= 3).  A hook that fired before its layer group's flush would average unreduced slabs --
     identically on both ranks, so only the comparison with the plain module chain notices;
   * stay in step -- three training steps with the one-launch Adam: bit-identical, finite parameters on both ranks."""
 import os
@@ -21,7 +21,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # (fused block nodes, deferred slab reductions, backward-weight stream mode)
-CONFIGS = [(True, True, 0), (False, True, 0), (True, False, 0), (False, False, 0), (True, True, 1)]
+CONFIGS = [(True, True, 0), (False, True, 0), (True, False, 0), (False, False, 0), (True, True, 1), (True, True, 3),
+           (False, True, 3)]
 
 
 def _worker(rank, world, port, q):
@@ -42,7 +43,7 @@ def _worker(rank, world, port, q):
     def set_config(fuse, defer, stream_mode):
         common._FUSE_BLOCKS = fuse
         be._wgrad_mode = stream_mode
-        be._wgrad_defer = bool(defer and stream_mode == 0)
+        be._wgrad_defer = bool(defer and stream_mode in (0, 3))
 
     def local_grads(model, batch):
         model.zero_grad(set_to_none=True)
@@ -66,8 +67,9 @@ def _worker(rank, world, port, q):
     errs = {}
     for cfg in CONFIGS:
         set_config(*cfg)
-        if cfg[1] and cfg[2] == 0:
-            assert be.wgrad_queue() is not None                       # the deferral is what runs below
+        if cfg[1] and cfg[2] in (0, 3):
+            q_ = be.wgrad_queue()
+            assert q_ is not None and q_.side_mode == (cfg[2] == 3)   # the deferral is what runs below
         model.zero_grad(set_to_none=True)
         sum(model._loss(batch, ddp(batch)).values()).backward()
         torch.cuda.synchronize()

@@ -359,7 +359,8 @@ def test_point_batchnorm_relu_matches_torch(C_):
 
 def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
     """MS3D_WGRAD_STREAM: the backward-weight kernels of every layer on a second stream beside the backward-data chain
-    (joined per layer = 1, or once at the end of the backward pass = 2) against the single-stream order: the same
+    (joined per layer = 1, once at the end of the backward pass = 2, or per layer group in its deferred-reduction node = 3)
+    against the single-stream order: the same
     kernels on the same data, so every gradient agrees (a missing join would show as garbage), also when the step is
     repeated back to back"""
     from minsu3d_amd import backend
@@ -373,7 +374,7 @@ def test_backward_weight_on_a_second_stream_gives_the_same_gradients():
     m.eval()                      # fixed BatchNorm statistics
     grads = {}
     try:
-        for mode in (0, 1, 2, 2):
+        for mode in (0, 1, 2, 2, 3, 3):
             be._wgrad_mode = mode
             m.zero_grad(set_to_none=True)
             sum(m._loss(b, m(b)).values()).backward()
