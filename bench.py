@@ -44,7 +44,7 @@ from minsu3d_amd.config import load_config  # noqa: E402
 from minsu3d_amd.data import synthetic  # noqa: E402
 import minsu3d_amd.model as ms_models  # noqa: E402
 import minsu3d_amd.MinkowskiEngine as ME  # noqa: E402
-from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, wrap_ddp  # noqa: E402
+from minsu3d_amd.parallel import init_distributed, shard_scene_seeds, stream_plan, wrap_ddp  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 MFMA (v_mfma_f32_16x16x4_f32), same guide / SURVEY 8d
@@ -419,6 +419,7 @@ def main(argv=None):
                                    f"(~{n_pts / 1000:.0f}k points, ~{n_vox / 1000:.0f}k voxels @2cm each), "
                                    f"{args.batch} scenes/GPU/step, grouping+ScoreNet branch on, fwd+loss+bwd+Adam",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "streams": stream_plan(world),
                        "grouping_inputs": "GT labels, GT offsets + N(0,4cm) (random-init net groups nothing)",
                        "input_pipelining": "coordinate-only work of step i+1's batch (row order, kernel maps, pair lists) "
                                            "runs on its own stream during step i's " +
@@ -451,7 +452,7 @@ def main(argv=None):
         if also != "none" and world == 1 and not dry:
             line["extra"] = {m: other_model_line(m, args) for m in also.split(",") if m and m != args.model}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -393,7 +393,7 @@ class GatherRowsFn(torch.autograd.Function):
             cached = getattr(idx, "_ms3d_sorted", None)
             queued = getattr(idx, "_ms3d_presort", None)
             if cached is not None and cached[2] == idx._version:
-                ctx.sorted = cached[:2]
+                ctx.sorted = cached               # the whole entry: it carries the event of the stream that sorted
             elif queued is not None and queued[1] == idx._version:
                 ctx.sorted = queued[0]            # a second gather over the same index (HAIS: features and mask scores)
             elif idx.numel() >= GatherRowsFn.PRESORT_MIN_ROWS:

@@ -38,6 +38,39 @@ def _i32(t):
 _HINT = object()   # placeholder in a C argument list: replaced by the capped/symmetric hint of the graph
 
 
+class _HandleTable:
+    """What the library knows about a tensor it produced (or was shown) that the reference's tensor-only operator
+    signatures (bfs_cluster.h:15-19) have no argument for: an entry per tensor OBJECT -- keyed by id() and guarded by a weak
+    reference (an address or an id may be recycled, a live object is not) and by the tensor's version counter (an in-place
+    write voids it).  Round 6: replaces the `_ms3d_capped` / `_ms3d_max_scene` attributes that rode on the
+    tensors themselves; a copy / slice / host round trip of the tensor is simply not in the table and takes the general
+    route (BFS: the validated one; ball query: one device->host read)."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def put(self, tensor, value):
+        import weakref
+        key = id(tensor)
+        entries = self._entries
+
+        def _gone(_ref, key=key, entries=entries):
+            e = entries.get(key)
+            if e is not None and e[0] is _ref:
+                del entries[key]
+        self._entries[key] = (weakref.ref(tensor, _gone), tensor._version, value)
+
+    def get(self, tensor, default=None):
+        e = self._entries.get(id(tensor))
+        if e is None or e[0]() is not tensor or e[1] != tensor._version:
+            return default
+        return e[2]
+
+
+GRAPHS = _HandleTable()        # start_len tensor of a ball query -> its `capped` flag (0 / 1)
+SCENE_BOUNDS = _HandleTable()  # batch_offsets tensor -> points of its largest scene
+
+
 class _Workspace:
     """grow-only device scratch, one per purpose (avoids hipMalloc on the hot path)"""
 
@@ -86,6 +119,11 @@ def prefetch_worker():
 
 
 def prefetch_stream(device):
+    # under data parallelism the prefetch shares the second grouping stream (parallel.stream_plan: at most three streams
+    # of this process beside the collective's -- inside the default four hardware queues)
+    from .parallel import stream_plan
+    if stream_plan()["prefetch_stream"] == "side":
+        return side_stream(device)
     s = _PF.get(device)
     if s is None:
         s = _PF[device] = torch.cuda.Stream(device=device)
@@ -175,13 +213,11 @@ class HipBackend:
             return torch.zeros(0, dtype=torch.int32, device=dev), start_len
         if max_scene_points <= 0:
             # tight per-scene bound -> smaller LDS bitmap, more waves per CU; the models query the same scene layout
-            # twice (shifted / original coordinates), so the value is remembered per offsets tensor
-            # (kept as an attribute of the tensor object: addresses are recycled by the allocator, objects are not)
-            cached = getattr(batch_offsets, "_ms3d_max_scene", None)
-            if cached is None or cached[0] != batch_offsets._version:
-                cached = (batch_offsets._version, int((batch_offsets[1:] - batch_offsets[:-1]).max().item()))
-                batch_offsets._ms3d_max_scene = cached
-            max_scene_points = cached[1]
+            # twice (shifted / original coordinates), so the value is remembered per offsets tensor (SCENE_BOUNDS)
+            max_scene_points = SCENE_BOUNDS.get(batch_offsets)
+            if max_scene_points is None:
+                max_scene_points = int((batch_offsets[1:] - batch_offsets[:-1]).max().item())
+                SCENE_BOUNDS.put(batch_offsets, max_scene_points)
         ws_bytes = self.lib.ms3d_ballquery_workspace_bytes(n)
         ws = self.ws.get("bq", ws_bytes, dev)
         n_active, capped = C.c_int(0), C.c_int(0)
@@ -210,12 +246,12 @@ class HipBackend:
             timer.op_end("ballquery_batch_p", ev0, n * 20 + n_active.value * (6.64 * 12 + 4))
         # remembered for the clustering call that consumes this graph: "no list reached the 1000 cap" means the graph
         # is symmetric, which lets the BFS skip a device->host check
-        start_len._ms3d_capped = int(capped.value)
+        GRAPHS.put(start_len, int(capped.value))
         return idx[:n_active.value], start_len
 
     # ------------------------------------------------------------------ BFS
     def _bfs(self, fn_name, args_head, ball_idx, start_len, args_tail):
-        hint = int(getattr(start_len, "_ms3d_capped", -1))   # set by ballquery_batch_p on the tensor it returned
+        hint = int(GRAPHS.get(start_len, -1))   # noted by ballquery_batch_p for the tensor it returned
         ball_idx = self._dev(ball_idx); start_len = self._dev(start_len)
         N = start_len.size(0)
         dev = start_len.device
@@ -253,7 +289,7 @@ class HipBackend:
 
     def hierarchical_aggregation(self, sem, coord_shift, ball_idx, start_len, batch_idxs, using_set_aggr,
                                  point_num_avg, radius_avg, ignored_label=-1):
-        hint = int(getattr(start_len, "_ms3d_capped", -1))   # set by ballquery_batch_p on the tensor it returned
+        hint = int(GRAPHS.get(start_len, -1))   # noted by ballquery_batch_p for the tensor it returned
         sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)
         start_len = self._dev(start_len); batch_idxs = self._dev(batch_idxs)
         assert sem.dtype == torch.int16 and batch_idxs.dtype == torch.uint8
@@ -280,7 +316,7 @@ class HipBackend:
         """the reference's own output contract (hierarchical_aggregation.cpp:105-184) -> dict of device tensors:
         kept / primary / fragment = (idxs [rows,2], offsets [n+1], centers [n,5]), post = (idxs [F+P rows,2] with a
         zero tail, offsets [n_primary+1]); fragment and post are None without set aggregation"""
-        hint = int(getattr(start_len, "_ms3d_capped", -1))
+        hint = int(GRAPHS.get(start_len, -1))
         sem = self._dev(sem); cs = self._dev(coord_shift); ball_idx = self._dev(ball_idx)
         start_len = self._dev(start_len); batch_idxs = self._dev(batch_idxs)
         assert sem.dtype == torch.int16 and batch_idxs.dtype == torch.uint8
@@ -383,11 +419,33 @@ class HipBackend:
         """(keys, order) of a STABLE ascending sort of an int64 row index, cached on the tensor: what the fixed-order
         scatter-add needs.  Callers that know the index ahead of its backward (the loader's voxel_point_map) call this
         early, off the critical path; torch's radix sort (rocPRIM) is plumbing, not a hot kernel."""
+        return self._use_sorted(self._sorted_cache(idx))
+
+    def _sorted_cache(self, idx):
+        """the cache entry (keys, order, version of idx, event recorded behind the sort, the stream it ran on): the sort is
+        often queued on the prefetch stream, so the entry carries its own ordering instead of relying on an unrelated
+        wait of the consumer"""
         cached = getattr(idx, "_ms3d_sorted", None)
         if cached is None or cached[2] != idx._version:
             keys, order = torch.sort(idx, stable=True)
-            cached = idx._ms3d_sorted = (keys, order, idx._version)
-        return cached[0], cached[1]
+            ev, st = None, None
+            if idx.is_cuda:
+                st = torch.cuda.current_stream(idx.device)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            cached = idx._ms3d_sorted = (keys, order, idx._version, ev, st)
+        return cached
+
+    @staticmethod
+    def _use_sorted(cached):
+        """(keys, order) of a cache entry, ordered behind its sort on the CURRENT stream"""
+        keys, order = cached[0], cached[1]
+        if len(cached) >= 5 and cached[3] is not None:
+            cur = torch.cuda.current_stream(keys.device)
+            if cur != cached[4]:
+                cur.wait_event(cached[3])
+                keys.record_stream(cur); order.record_stream(cur)
+        return keys, order
 
     def presort_rows(self, idx):
         """Scheduling only: the stable sort of `idx` queued on the helper thread and the side stream NOW (the forward of
@@ -426,7 +484,7 @@ class HipBackend:
             cur.wait_event(done)
             keys.record_stream(cur); order.record_stream(cur); idx.record_stream(sorted_[1])
         elif sorted_ is not None:
-            keys, order = sorted_
+            keys, order = self._use_sorted(sorted_)
         else:
             keys, order = self.sorted_rows(idx)
         _lib.check(self.lib.ms3d_scatter_add_rows_sorted(_lib.ptr(src), _lib.ptr(keys), _lib.ptr(order),

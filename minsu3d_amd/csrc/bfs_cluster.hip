@@ -276,9 +276,10 @@ __global__ void bfs_validate_kernel(int N, long n_edges, const int *__restrict__
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    if (t < N) {
-        const long st = start_len[t * 2], ln = start_len[t * 2 + 1];
-        bad = st < 0 || ln < 0 || st + ln > n_edges;
+    // both parts grid-stride: the grid is capped at 2^20 threads, N is not (headers past the cap went unchecked)
+    for (long i = t; i < N; i += (long)gridDim.x * blockDim.x) {
+        const long st = start_len[i * 2], ln = start_len[i * 2 + 1];
+        bad |= st < 0 || ln < 0 || st + ln > n_edges;
     }
     for (long e = t; e < n_edges; e += (long)gridDim.x * blockDim.x) {
         const int j = ball_idx[e];

@@ -44,6 +44,12 @@ static hipError_t raise_lds_ceiling(const void *fn)
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
 }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 struct ConvArgs {
     const float *in;         // [Vin, Cin]
     const float *wf;         // fragment-major weights
@@ -76,6 +82,11 @@ struct ConvArgs {
     const int *pl_entries;
     int dyn_picks;             // pair-list kernels: tiles picked off an LDS counter (MS3D_PL_DYNAMIC=1) instead of the fixed schedule
     int k1_path;               // K = 1: bit 0 = accumulate_k1 in the LDS-resident table walk, bit 1 = in the small-level kernel
+    // weight-stationary kernels of the coarse levels (spconv_fwd_ws_kernel): partial-sum slabs [ws_ng][ntiles][NBtot][64] x 16 B,
+    // one arrival counter per (row part, column slice) unit (zero between launches), offsets per group, row parts, tiles per part
+    float *ws_slabs;
+    unsigned *ws_cnt;
+    int ws_ng, ws_kg, ws_R, ws_tpp;
 };
 
 // ------------------------------------------------------------------ weight permutation
@@ -1198,6 +1209,239 @@ int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool align
     else if (res) MS3D_FWD_LAUNCH(false, true);
     else MS3D_FWD_LAUNCH(false, false);
 #undef MS3D_FWD_LAUNCH
+    MS3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight-stationary kernels of the coarse levels (round 6)
+// Levels with <= ~3k output rows (L4-L6 of the backbone: 2.5k / 500 / 112 rows at 80..224 channels, and the 2c -> c layers
+// behind their concatenations).  The one-tile kernels above hand every 16-row tile the whole column slice of the weight
+// image: 160 -> 160 at 2.6k rows streams 162 x 2.8 MB through L2 for 3 MB of rows, and a launch is a chain of ~45 dependent
+// L2 round trips per wave.  Here the WEIGHTS stay put:
+//   block  = (offset group g of kg offsets, column slice c of NBT blocks, row part r of tpp tiles); its slab
+//            W[k_lo..k_lo+kg)[all Cin][NBT*16] (<= 64 KB, two blocks per CU) is copied into LDS ONCE and every tile of the part
+//            runs through it -- weights leave L2 (row parts) x |W| per launch instead of (tiles) x |W|;
+//   wave   = tiles w, w + 4, .. of the part; per tile the (offset, 16-channel chunk) items of the group are walked in ONE flat
+//            sequence, WS_RB row gathers in flight and the next WS_RB behind them (two register sets): a tile costs two
+//            dependent round trips (table entries -- fetched a tile ahead -- and rows) whatever Cin is; B fragments are
+//            conflict-free ds_read_b32 rows of the slab; offsets no row of the tile has skip their MFMAs;
+//   split-K: the ng = ceil(K / kg) groups of a unit (c, r) leave their partial tiles in a slab area (16 B per lane,
+//            accumulator layout) and draw a ticket; the block that draws the LAST ticket adds the ng partials of every tile
+//            in GROUP order (not arrival order: bit-reproducible), and runs the usual epilogue (residual / bias / statistics /
+//            fused BatchNorm-backward mask and sums).  Hand-off as the CDNA4 guide prescribes for an in-launch split-K: plain
+//            16-byte stores -> per-wave vmcnt(0) -> barrier -> ONE lane: agent-scope release fence, vmcnt(0), relaxed agent
+//            fetch_add; the last arriver: ONE agent-scope acquire -> barrier -> plain loads.  Correct for any placement of a
+//            unit's blocks; for speed the block id puts them on one XCD (id & 7 = unit & 7) and next to each other in dispatch
+//            order.  The last arriver zeroes the counter for the next launch on the stream.
+// (WS_RB row gathers in flight per register set: 8 in the <= 8-wave form, 4 in the 16-wave form whose waves have 128 registers)
+
+struct WsBlock { int u, g, nb0, k_lo, kcnt, t_begin, t_end; };
+
+template <int NBT>
+__device__ __forceinline__ bool ws_block(const ConvArgs &p, WsBlock &b)
+{
+    const int ny = p.NBtot / NBT, units = p.ws_R * ny;
+    const int id = (int)blockIdx.x;
+    b.u = (id / (8 * p.ws_ng)) * 8 + (id & 7);
+    b.g = (id >> 3) % p.ws_ng;
+    if (b.u >= units) return false;
+    const int c = b.u % ny, r = b.u / ny;
+    b.nb0 = c * NBT;
+    b.k_lo = b.g * p.ws_kg;
+    b.kcnt = min(p.K, b.k_lo + p.ws_kg) - b.k_lo;
+    b.t_begin = r * p.ws_tpp;
+    b.t_end = min(p.ntiles, b.t_begin + p.ws_tpp);
+    return true;
+}
+
+__device__ __forceinline__ f32x4 *ws_slab_ptr(const ConvArgs &p, int g, int tile, int nb)
+{
+    return reinterpret_cast<f32x4 *>(p.ws_slabs) + (((size_t)g * p.ntiles + tile) * p.NBtot + nb) * 64 + lane_id();
+}
+
+// after the block's tile loop (ng > 1): publish, draw the ticket, and -- last arriver -- combine + epilogue
+template <int NBT>
+__device__ __forceinline__ void ws_finish(const ConvArgs &p, const WsBlock &b, float *s_part, int *s_flag)
+{
+    const int w = wave_id(), waves = blockDim.x >> 6;
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (p.ws_ng > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(&p.ws_cnt[b.u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)(p.ws_ng - 1);
+            if (last) {
+                __hip_atomic_store(&p.ws_cnt[b.u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch on this stream
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *s_flag = last;
+        }
+        __syncthreads();
+        if (!*s_flag) return;
+        float *slot = s_part + (size_t)w * stat_slot_floats(NBT);
+        for (int tile = b.t_begin + w; tile < b.t_end; tile += waves) {
+            // GB groups' partials requested together (unconditional, clamped), added in group order
+            constexpr int GB = NBT <= 2 ? 8 : 4;
+            f32x4 sum[NBT];
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) sum[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int g0 = 0; g0 < p.ws_ng; g0 += GB) {
+                f32x4 v[GB][NBT];
+#pragma unroll
+                for (int j = 0; j < GB; j++)
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) v[j][nb] = *ws_slab_ptr(p, min(g0 + j, p.ws_ng - 1), tile, b.nb0 + nb);
+#pragma unroll
+                for (int j = 0; j < GB; j++) {
+                    if (g0 + j >= p.ws_ng) break;
+#pragma unroll
+                    for (int nb = 0; nb < NBT; nb++) sum[nb] += v[j][nb];
+                }
+            }
+            store_tile<NBT>(p, tile * 16, b.nb0, sum, slot);
+        }
+    }
+    if (with_partial) {
+        // one statistics row per unit (ms3d_spconv_partial_blocks counts R x ny): the slots in wave order, other slices' columns zero
+        __syncthreads();
+        float *dst = p.bn_partial + (size_t)b.u * 2 * p.Cout;
+        for (int t = threadIdx.x; t < 2 * p.Cout; t += blockDim.x) {
+            const int which = t >= p.Cout, c = t - which * p.Cout - 16 * b.nb0;
+            float sum = 0.f;
+            if (c >= 0 && c < NBT * 16)
+                for (int ww = 0; ww < waves; ww++) sum += s_part[(size_t)ww * stat_slot_floats(NBT) + which * NBT * 16 + c];
+            dst[t] = sum;
+        }
+    }
+}
+
+template <int NBT, int WS_RB, int MAXT>
+__global__ __launch_bounds__(MAXT) void spconv_fwd_ws_kernel(ConvArgs p)
+{
+    extern __shared__ float lds[];
+    WsBlock b;
+    if (!ws_block<NBT>(p, b)) return;
+    const int l = lane_id(), q = l >> 4, il = l & 15, w = wave_id(), waves = blockDim.x >> 6;
+    // LDS: weights [kg][NCH][4][NBT][64] | scale[16 NCH] | shift[16 NCH] | table entries [waves][kg][16] | statistics slots | flag
+    float *sW = lds;
+    float *s_scale = sW + (size_t)p.ws_kg * p.NCH * 4 * NBT * 64;
+    float *s_shift = s_scale + p.NCH * 16;
+    int *s_idx = reinterpret_cast<int *>(s_shift + p.NCH * 16);
+    float *s_part = reinterpret_cast<float *>(s_idx + waves * p.ws_kg * 16);
+    int *s_flag = reinterpret_cast<int *>(s_part + (size_t)waves * stat_slot_floats(NBT));
+    {
+        const int rows = b.kcnt * p.NCH * 4, slab4 = NBT * 16;
+        const float *src = p.wf + ((size_t)b.k_lo * p.NCH * 4 * p.NBtot + b.nb0) * 64;
+        for (int e = threadIdx.x; e < rows * slab4; e += blockDim.x) {
+            const int r = e / slab4, c4 = e - r * slab4;
+            reinterpret_cast<f32x4 *>(sW)[e] = reinterpret_cast<const f32x4 *>(src + (size_t)r * p.NBtot * 64)[c4];
+        }
+        if (p.pre_scale)
+            for (int e = threadIdx.x; e < p.Cin; e += blockDim.x) { s_scale[e] = p.pre_scale[e]; s_shift[e] = p.pre_shift[e]; }
+    }
+    const bool with_partial = p.bn_x != nullptr || p.out_stats != 0;
+    if (with_partial) stats_clear<NBT>(s_part, waves);
+    __syncthreads();
+    const bool affine = p.pre_scale != nullptr;
+    int *my_idx = s_idx + w * p.ws_kg * 16;
+    const int nitems = b.kcnt * p.NCH;
+    constexpr int NI = 3;                               // table entries per lane: offsets q, q + 4, q + 8 (kg <= 12)
+    auto load_entries = [&](int tile, int (&e)[NI]) {
+        const int row = tile * 16 + il;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int uu = q + 4 * j;
+            const bool ok = uu < b.kcnt && row < p.Vout && tile < b.t_end;
+            const int v = p.nbr[(size_t)(b.k_lo + (uu < b.kcnt ? uu : 0)) * p.Vout + (row < p.Vout ? row : 0)];
+            e[j] = v | (ok ? 0 : -1);
+        }
+    };
+    int ent[NI];
+    load_entries(b.t_begin + w, ent);
+    for (int tile = b.t_begin + w; tile < b.t_end; tile += waves) {
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+            if (q + 4 * j < p.ws_kg) my_idx[(q + 4 * j) * 16 + il] = ent[j];
+        load_entries(tile + waves, ent);                // the next tile's entries travel under this tile's work
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // item = (offset uu of the group, 16-channel chunk ch), walked as one flat sequence; (fu, fc) = the fetch cursor,
+        // (cu, cc) = the compute cursor
+        int fu = 0, fc = 0, cu = 0, cc = 0;
+        auto fetch = [&](int i0, f32x4 (&a)[WS_RB], int (&ri)[WS_RB]) {
+#pragma unroll
+            for (int j = 0; j < WS_RB; j++) {
+                const bool live = i0 + j < nitems;
+                const int r = my_idx[min(fu, b.kcnt - 1) * 16 + il] | (live ? 0 : -1);
+                ri[j] = r;
+                a[j] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)max(r, 0) * p.Cin + 16 * fc + 4 * q);
+                if (live) { fc++; if (fc == p.NCH) { fc = 0; fu++; } }
+            }
+        };
+        auto compute = [&](int i0, f32x4 (&a)[WS_RB], const int (&ri)[WS_RB]) {
+#pragma unroll
+            for (int j = 0; j < WS_RB; j++) {
+                if (i0 + j >= nitems) break;
+                const bool any = __ballot(ri[j] >= 0) != 0ull;
+                if (any) {
+                    f32x4 v = a[j];
+                    if (affine) {
+                        const f32x4 s = *reinterpret_cast<const f32x4 *>(s_scale + 16 * cc + 4 * q);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(s_shift + 16 * cc + 4 * q);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float z = fmaf(v[t], s[t], sh[t]);
+                            v[t] = p.pre_relu ? fmaxf(z, 0.f) : z;
+                        }
+                    }
+                    const int keep = ~(ri[j] >> 31);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] = __int_as_float(__float_as_int(v[t]) & keep);
+                    const float *wp = sW + (size_t)((cu * p.NCH + cc) * 4) * NBT * 64 + l;
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int nb = 0; nb < NBT; nb++)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], wp[(t * NBT + nb) * 64], acc[nb], 0, 0, 0);
+                }
+                cc++; if (cc == p.NCH) { cc = 0; cu++; }
+            }
+        };
+        f32x4 a0[WS_RB], a1[WS_RB];
+        int r0[WS_RB], r1[WS_RB];
+        fetch(0, a0, r0);
+        for (int i0 = 0; i0 < nitems; i0 += 2 * WS_RB) {
+            fetch(i0 + WS_RB, a1, r1);
+            compute(i0, a0, r0);
+            fetch(i0 + 2 * WS_RB, a0, r0);
+            compute(i0 + WS_RB, a1, r1);
+        }
+        if (p.ws_ng == 1) {
+            store_tile<NBT>(p, tile * 16, b.nb0, acc, s_part + (size_t)w * stat_slot_floats(NBT));
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) *ws_slab_ptr(p, b.g, tile, b.nb0 + nb) = acc[nb];
+        }
+    }
+    ws_finish<NBT>(p, b, s_part, s_flag);
+}
+
+template <int NBT>
+int launch_fwd_ws(const ConvArgs &p, int nblk, int threads, size_t lds, hipStream_t stream)
+{
+    if (threads > 512) {
+        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_ws_kernel<NBT, 4, 1024>);
+        MS3D_CHECK(attr);
+        spconv_fwd_ws_kernel<NBT, 4, 1024><<<nblk, threads, lds, stream>>>(p);
+    } else {
+        static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_ws_kernel<NBT, 8, 512>);
+        MS3D_CHECK(attr);
+        spconv_fwd_ws_kernel<NBT, 8, 512><<<nblk, threads, lds, stream>>>(p);
+    }
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -2422,8 +2666,12 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     __shared__ int s_lo[32], s_cum[33], s_pk[16][2];
     const int l = lane_id(), q = l >> 4, cl = l & 15;
     const int nw = blockDim.x >> 6, w = wave_id();
-    float *s_part = lds;                                                          // [nw][2][NA*256]
-    float *s_tile = lds + (size_t)nw * 2 * NA * 256 + (size_t)w * TB * NT * 256;  // [TB][NCH + NBT][16 pairs][16]
+    // per wave: [TB][NCH + NBT][16 pairs][16] transposition tiles; once the wave's pair loop is over the same area takes its (at
+    // most two) boundary partials [2][NA*256] -- 2 NA <= TB (NCH + NBT) for every instantiation.  (Rounds 1-5 kept a separate
+    // [nw][2][NA*256] area: 8 of the 18 KB per wave at 64 -> 64, which left 8 waves per CU -- round 6 counters: 44 % of the wave
+    // cycles waiting, MFMA pipe 36 % busy.)  The FIRST partial of a wave is done long before its loop ends: it waits in registers.
+    static_assert(2 * NA <= TB * NT, "boundary partials reuse the transposition tiles");
+    float *s_tile = lds + (size_t)w * TB * NT * 256;
     const int tiles = (p.Vout + MS3D_PL_ROWS - 1) / MS3D_PL_ROWS;
     // tile range of this workgroup: 2^rows_per_block consecutive parts of the list's equal-pair-count cut
     const int *__restrict__ part_start = p.ol_kt_start + (size_t)p.K * tiles + 1;
@@ -2442,6 +2690,12 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     if (threadIdx.x < 32) s_pk[threadIdx.x >> 1][threadIdx.x & 1] = -1;
     __syncthreads();
 
+    // Transposition tiles are [16 pairs][4 chunks of 16 B]: row `cl` keeps chunk q at slot q ^ ((cl >> 1) & 3).  Unswizzled,
+    // the eight lanes of a ds_write_b128 group (same q, pairs 0-7 / 8-15) are 64 B apart and hit two 16-byte bank ranges of
+    // the 32-bank store path: 4-way conflicts on every park (round 6 counters: SQ_LDS_BANK_CONFLICT 61 M cycles per
+    // 64 -> 64 launch at 196k rows, a third of the LDS time); the transposed ds_read_b32 (rows 4st+q, two rows per 32-lane
+    // group that share (row >> 1)) stays a permutation of 32 consecutive dwords.
+    const int qs = q ^ ((cl >> 1) & 3);
     const int cbase = blockIdx.z * NCH * 16;  // first input channel of this workgroup
     const int col0 = blockIdx.y * NBT * 16;   // first output column (round 5: layers beyond 64 output channels in slices of NBT blocks)
     f32x4 sc[NCH], sh[NCH];
@@ -2472,6 +2726,10 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     const int T = s_cum[p.K];
     const int s0 = (int)((long long)T * w / nw), s1 = (int)((long long)T * (w + 1) / nw);
     int n_partial = 0;
+    f32x4 part0[NA];          // the slice's first cut offset
+    int pk0 = -1;
+#pragma unroll
+    for (int b = 0; b < NA; b++) part0[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.K; k++) {
         const int c_lo = s_cum[k], c_hi = s_cum[k + 1];
         const int g_lo = max(s0, c_lo), g_hi = min(s1, c_hi);
@@ -2531,11 +2789,11 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
                         }
                         ca[t][ch][i] = ch_ok ? v : 0.f;
                     }
-                    *reinterpret_cast<f32x4 *>(ta + ch * 256 + cl * 16 + 4 * q) = ca[t][ch];
+                    *reinterpret_cast<f32x4 *>(ta + ch * 256 + cl * 16 + 4 * qs) = ca[t][ch];
                 }
 #pragma unroll
                 for (int nb = 0; nb < NBT; nb++)
-                    *reinterpret_cast<f32x4 *>(ta + (NCH + nb) * 256 + cl * 16 + 4 * q) = cb[t][nb];
+                    *reinterpret_cast<f32x4 *>(ta + (NCH + nb) * 256 + cl * 16 + 4 * qs) = cb[t][nb];
             }
 #pragma unroll
             for (int t = 0; t < TB; t++) {
@@ -2544,10 +2802,10 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
                 for (int st = 0; st < 4; st++) {
                     float bv[NBT];
 #pragma unroll
-                    for (int nb = 0; nb < NBT; nb++) bv[nb] = ta[(NCH + nb) * 256 + (4 * st + q) * 16 + cl];  // B[k = pair][n = co cl]
+                    for (int nb = 0; nb < NBT; nb++) bv[nb] = ta[(NCH + nb) * 256 + (4 * st + q) * 16 + (cl ^ (((2 * st + (q >> 1)) & 3) << 2))];  // B[k = pair][n = co cl]
 #pragma unroll
                     for (int ch = 0; ch < NCH; ch++) {
-                        const float av = ta[ch * 256 + (4 * st + q) * 16 + cl];  // A[m = ci cl][k = pair 4st + q]
+                        const float av = ta[ch * 256 + (4 * st + q) * 16 + (cl ^ (((2 * st + (q >> 1)) & 3) << 2))];  // A[m = ci cl][k = pair 4st + q]
 #pragma unroll
                         for (int nb = 0; nb < NBT; nb++)
                             acc[ch * NBT + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[ch * NBT + nb], 0, 0, 0);
@@ -2557,8 +2815,15 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
         }
         if (g_lo == c_lo && g_hi == c_hi) {
             store_slab(k, acc);
+        } else if (n_partial == 0 && g_hi < s1) {
+            // cut at the FRONT of the slice and more offsets follow: parked in registers until the tiles are free
+#pragma unroll
+            for (int b = 0; b < NA; b++) part0[b] = acc[b];
+            pk0 = k;
+            n_partial = 1;
         } else {
-            float *dst = s_part + (size_t)(w * 2 + n_partial) * NA * 256;
+            // the slice ends inside this offset: nothing follows, the tile area is free
+            float *dst = s_tile + (size_t)n_partial * NA * 256;
 #pragma unroll
             for (int b = 0; b < NA; b++)
 #pragma unroll
@@ -2566,6 +2831,13 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
             if (l == 0) s_pk[w][n_partial] = k;
             n_partial++;  // at most 2: the offsets cut by the two ends of the slice
         }
+    }
+    if (pk0 >= 0) {
+#pragma unroll
+        for (int b = 0; b < NA; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_tile[b * 256 + r * 64 + l] = part0[b][r];
+        if (l == 0) s_pk[w][0] = pk0;
     }
     __syncthreads();
     // offsets cut by slice boundaries (partials summed in wave order) and offsets without pairs in this chunk (zeros)
@@ -2579,7 +2851,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
             for (int jj = 0; jj < 2; jj++)
                 if (s_pk[ww][jj] == k) {
                     any = true;
-                    const float *src = s_part + (size_t)(ww * 2 + jj) * NA * 256;
+                    const float *src = lds + (size_t)ww * TB * NT * 256 + (size_t)jj * NA * 256;
 #pragma unroll
                     for (int b = 0; b < NA; b++)
 #pragma unroll
@@ -2592,10 +2864,12 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
 template <int NBT, int NCH>
 int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 {
-    // per wave: WGRAD_TB x (NCH + NBT) transposition tiles + 2 x NCH*NBT boundary partials, 1 KB each
-    const size_t per_wave = ((size_t)WGRAD_TB * (NCH + NBT) + 2 * NCH * NBT) * 256 * sizeof(float);
+    // per wave: WGRAD_TB x (NCH + NBT) transposition tiles of 1 KB (the boundary partials reuse them)
+    const size_t per_wave = (size_t)WGRAD_TB * (NCH + NBT) * 256 * sizeof(float);
+    static const int max_w = env_int("MS3D_WGRAD_LIST_WAVES", 16);
     int nw = (int)(LDS_BUDGET / per_wave);
     if (nw > 16) nw = 16;
+    if (nw > max_w && max_w >= 1) nw = max_w;
     dim3 grid(nblk_rows, ms3d_divup(p.NBtot, NBT), ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
     const size_t lds = (size_t)nw * per_wave;
     static const hipError_t attr = raise_lds_ceiling((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>);
@@ -3055,7 +3329,95 @@ struct FwdGeom {
     size_t lds;
     bool ok, small, pairlist, stream;
     int cg;   // stream kernel: 16-channel chunks per weight group
+    bool ws;  // weight-stationary kernel of the coarse levels: ws_ng offset groups of ws_kg, ws_R row parts of ws_tpp tiles
+    int ws_ng, ws_kg, ws_R, ws_tpp;
 };
+// Weight-stationary route (spconv_fwd_ws_kernel): levels of at most MS3D_WS_MAX_TILES 16-row tiles (default 220 = 3.5k rows;
+// 0 switches the route off), 48+ channels on both sides, K > 1.  The geometry must not depend on anything but the layer
+// shape: ms3d_spconv_partial_blocks sizes the statistics partials from it before the launch.
+bool ws_geometry(int Vout, int K, int Cin, int Cout, FwdGeom &g)
+{
+    static const int max_tiles = env_int("MS3D_WS_MAX_TILES", 220);
+    static const int env_nbt = env_int("MS3D_WS_NBT", 0);
+    static const int lds_kb = env_int("MS3D_WS_LDS_KB", 128);
+    static const int target_blocks = env_int("MS3D_WS_BLOCKS", 1024);
+    static const int min_tpp = env_int("MS3D_WS_MIN_TPP", 4);
+    // MS3D_WS_ALL=1: every shape the kernel can serve (tests, measurements).  Default: only where it was measured to win --
+    // K = 27 layers with a side beyond 256 channels (no three-piece bf16 image exists for them: 320 -> 160 and its
+    // backward-data twin at the 2.5k-row level of the m = 32 models) on levels of 64+ tiles.  Measured, us per launch, this
+    // route | one-tile kernels (profiles/r06_ws_*.txt): 320 -> 160 at 2.5k rows 136 | 162; but 160 -> 160 79 | 87 (f32) | 60
+    // (bf16x3), 80 -> 80 32 | 26, 192 -> 192 at 493 rows 35 | 31, 384 -> 192 78 | 58, 96 -> 96 17.5 | 12.5, 224 -> 224 at
+    // 112 rows 22.6 | 21.0: the one-tile kernels are NOT bound by re-streaming the weights (L2 hit rate 94 %, 134-cycle
+    // average L2 latency, profiles/r06_conv_counters.txt) and this route pays a staging round trip, a release fence and a
+    // combine pass on top of the same f32 MFMA time.
+    static const int ws_all = env_int("MS3D_WS_ALL", 0);
+    const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16), ntiles = ms3d_divup(Vout, 16);
+    if (max_tiles <= 0 || ntiles > max_tiles || K < 2 || K > 27 || Cin % 16 || Cout % 16 || Cin < 48 || Cout < 48 || Cin > 512) return false;
+    if (!ws_all && !(K == 27 && (Cin > 256 || Cout > 256) && Cin >= 160 && ntiles >= 64)) return false;
+    int nbt = NBtot % 2 == 0 ? 2 : (NBtot % 3 == 0 ? 3 : 1);
+    if (env_nbt >= 1 && env_nbt <= 4 && NBtot % env_nbt == 0) nbt = env_nbt;
+    static const int env_waves = env_int("MS3D_WS_WAVES", 16);
+    const int waves = env_waves < 1 ? 1 : (env_waves > 16 ? 16 : env_waves);
+    for (;; ) {
+        const size_t per_offset = (size_t)NCH * 4 * nbt * 64 * sizeof(float);
+        const size_t fixed = (size_t)2 * NCH * 16 * sizeof(float) + (size_t)waves * 12 * 16 * sizeof(int) +
+                             waves * stat_slot_floats(nbt) * sizeof(float) + 16;
+        int kg = (int)(((size_t)lds_kb * 1024 - fixed) / per_offset);
+        if (kg < 1) {
+            if (nbt == 1) return false;
+            nbt = 1;                       // very wide input side: one column block per slice
+            continue;
+        }
+        if (kg > 12) kg = 12;             // table entries per tile: three per lane
+        if (kg > K) kg = K;
+        const int ng = ms3d_divup(K, kg);
+        kg = ms3d_divup(K, ng);
+        const int ny = NBtot / nbt;
+        int R = target_blocks / (ng * ny);
+        if (R < 1) R = 1;
+        int tpp = ms3d_divup(ntiles, R);
+        if (tpp < min_tpp) tpp = min_tpp;
+        R = ms3d_divup(ntiles, tpp);
+        g = FwdGeom{};
+        g.ws = true;
+        g.ok = true;
+        g.nbt = nbt; g.ny = ny; g.threads = waves * 64;
+        g.nblk = R;                        // statistics partial rows = R x ny (one per unit)
+        g.G = K; g.rt = 1;
+        g.ws_ng = ng; g.ws_kg = kg; g.ws_R = R; g.ws_tpp = tpp;
+        g.lds = per_offset * kg + (size_t)2 * NCH * 16 * sizeof(float) + (size_t)waves * kg * 16 * sizeof(int) +
+                waves * stat_slot_floats(nbt) * sizeof(float) + 16;
+        return true;
+    }
+}
+// slab area + arrival counters of the weight-stationary kernels, one per (device, stream), grown on demand (a launch on a
+// stream is ordered behind the previous one, so one area per stream is enough); counters are zero between launches
+struct WsSpace { float *slabs = nullptr; size_t slab_floats = 0; unsigned *cnt = nullptr; int ncnt = 0; };
+WsSpace *ws_space(hipStream_t stream, size_t need_floats, int need_cnt)
+{
+    static std::mutex lock;
+    static std::map<std::pair<int, hipStream_t>, WsSpace> spaces;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    WsSpace &sp = spaces[{dev, stream}];
+    if (need_floats > sp.slab_floats) {
+        if (sp.slabs) { if (hipStreamSynchronize(stream) != hipSuccess || hipFree(sp.slabs) != hipSuccess) return nullptr; }
+        sp.slabs = nullptr; sp.slab_floats = 0;
+        const size_t n = need_floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : need_floats + need_floats / 2;   // >= 32 MB
+        if (hipMalloc((void **)&sp.slabs, n * sizeof(float)) != hipSuccess) return nullptr;
+        sp.slab_floats = n;
+    }
+    if (need_cnt > sp.ncnt) {
+        if (sp.cnt) { if (hipStreamSynchronize(stream) != hipSuccess || hipFree(sp.cnt) != hipSuccess) return nullptr; }
+        sp.cnt = nullptr; sp.ncnt = 0;
+        const int n = need_cnt < 4096 ? 4096 : 2 * need_cnt;
+        if (hipMalloc((void **)&sp.cnt, (size_t)n * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(sp.cnt, 0, (size_t)n * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+        sp.ncnt = n;
+    }
+    return &sp;
+}
 constexpr int PAIRLIST_MIN_ROWS = 30000;  // below this the 16-row kernels win (weight staging per block dominates)
 int pairlist_min_rows()
 {
@@ -3121,6 +3483,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
         const char *e = getenv("MS3D_SMALL_TILES");  // tuning knob; default measured on MI355X
         return e ? atoi(e) : SMALL_TILES;
     }();
+    if (ws_geometry(Vout, K, Cin, Cout, g)) return g;
     if (ntiles <= small_tiles && (size_t)NCH * NBtot >= 4) {
         // one block per (tile, column slice); waves = offset groups; enough column splits for ~1024+ waves
         const int ks = ms3d_divup(K, OG);
@@ -3347,6 +3710,22 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
     const bool aligned = (Cin % 16 == 0);
+    p.ws_slabs = nullptr; p.ws_cnt = nullptr; p.ws_ng = p.ws_kg = p.ws_R = p.ws_tpp = 0;
+    if (g.ws) {
+        const int units = g.ws_R * g.ny;
+        WsSpace *sp = ws_space(stream, g.ws_ng > 1 ? (size_t)g.ws_ng * p.ntiles * p.NBtot * 256 : 0, units);
+        if (!sp) return (int)hipErrorOutOfMemory;
+        p.ws_slabs = sp->slabs; p.ws_cnt = sp->cnt;
+        p.ws_ng = g.ws_ng; p.ws_kg = g.ws_kg; p.ws_R = g.ws_R; p.ws_tpp = g.ws_tpp;
+        const int nblk = ms3d_divup(units, 8) * 8 * g.ws_ng;
+        switch (g.nbt) {
+            case 1: return launch_fwd_ws<1>(p, nblk, g.threads, g.lds, stream);
+            case 2: return launch_fwd_ws<2>(p, nblk, g.threads, g.lds, stream);
+            case 3: return launch_fwd_ws<3>(p, nblk, g.threads, g.lds, stream);
+            case 4: return launch_fwd_ws<4>(p, nblk, g.threads, g.lds, stream);
+        }
+        return MS3D_E_UNSUPPORTED;
+    }
     if (g.stream) {
         if (!wf_stream || aux_kind != 1) return MS3D_E_UNSUPPORTED;  // the geometry (and the caller's partial buffer) assume this kernel
         p.wfs = wf_stream;

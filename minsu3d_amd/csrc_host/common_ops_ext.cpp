@@ -16,6 +16,7 @@
 //
 // minsu3d_amd/dropin/COMMON_OPS.py is the same module over ctypes (the fallback when this extension is not built).
 #include <torch/extension.h>
+#include <mutex>
 #include <c10/hip/HIPStream.h>
 
 #include <vector>
@@ -51,13 +52,18 @@ inline at::Tensor scratch(size_t bytes, const at::Tensor &like)
 // the last ball query's "no list reached the 1000 cap" flag, keyed by the start_len buffer it wrote: lets the BFS that
 // consumes that very graph skip a device->host check (-1 = unknown: decided on the device)
 struct LastGraph { const void *start_len = nullptr; int n = 0; int capped = -1; } g_last;
+std::mutex g_last_lock;   // ball queries and their consumers may run on several host threads
 
 // ONE use per ball query: the key is an address and a length, and the caching allocator may hand the same
 // address to a later start_len of equal length (or the caller may edit the tensor in place); the grouping that follows a
 // query consumes the hint, anything later decides on the device
 inline int capped_hint(const at::Tensor &start_len_dev)
 {
-    const int hint = (g_last.start_len == start_len_dev.data_ptr() && g_last.n == start_len_dev.size(0)) ? g_last.capped : -1;
+    // consumed by the call that MATCHES it only: an unrelated clustering call in between (another thread's graph, a host
+    // graph) takes the validated general route for itself and leaves the hint for the grouping it belongs to
+    std::lock_guard<std::mutex> guard(g_last_lock);
+    if (g_last.start_len != start_len_dev.data_ptr() || g_last.n != start_len_dev.size(0)) return -1;
+    const int hint = g_last.capped;
     g_last = LastGraph();
     return hint;
 }
@@ -79,9 +85,12 @@ int ballquery_batch_p(at::Tensor xyz, at::Tensor batch_idxs, at::Tensor batch_of
                                  (int)o.numel() - 1, 0, idx.data_ptr<int>(), start_len.data_ptr<int>(), &n_active, &capped,
                                  ws.data_ptr(), (size_t)ws.numel(), cur()),
           "ms3d_ballquery_batch_p");
-    g_last.start_len = start_len.data_ptr();
-    g_last.n = (int)start_len.size(0);
-    g_last.capped = capped;
+    {
+        std::lock_guard<std::mutex> guard(g_last_lock);
+        g_last.start_len = start_len.data_ptr();
+        g_last.n = (int)start_len.size(0);
+        g_last.capped = capped;
+    }
     return n_active;
 }
 

@@ -20,6 +20,7 @@ import ctypes as C
 import torch
 
 from minsu3d_amd import _lib
+from minsu3d_amd import backend as _backend
 from minsu3d_amd.backend import get_backend
 
 __all__ = ["sg_bfs_cluster", "global_avg_pool_fp", "global_avg_pool_bp", "ballquery_batch_p", "sec_mean", "sec_min",
@@ -60,7 +61,7 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, meanAct
         n, int(meanActive), C.c_float(radius), _lib.ptr(xyz), _lib.ptr(batch_idxs), _lib.ptr(batch_offsets),
         int(batch_offsets.numel() - 1), 0, _lib.ptr(idx), _lib.ptr(start_len), C.byref(n_active), C.byref(capped),
         _lib.ptr(ws), C.c_size_t(ws.numel()), _lib.stream_handle()), "ms3d_ballquery_batch_p")
-    start_len._ms3d_capped = int(capped.value)
+    _backend.GRAPHS.put(start_len, int(capped.value))
     _remember_graph(idx, start_len, int(n_active.value), int(capped.value))
     return int(n_active.value)
 
@@ -123,7 +124,7 @@ def _device_graph(ball_query_idxs, start_len):
             if host_sums == (g["sum_idx"], g["sum_sl"]):
                 _REUSE_HITS[0] += 1
                 sl = g["start_len"]
-                sl._ms3d_capped = g["capped"]
+                _backend.GRAPHS.put(sl, g["capped"])
                 del _GRAPHS[k]                     # used once: the 150 MB list is not kept alive for another step
                 return g["idx"][:g["n_active"]], sl
     _REUSE_HITS[1] += 1

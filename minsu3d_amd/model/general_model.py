@@ -162,7 +162,6 @@ class GeneralModel(nn.Module):
         heads' backward is ~0.6 ms of kernels issued through ~80 autograd nodes, i.e. ~0.7 ms of interpreter time that moves
         from the GPU-bound backward pass (where the host is milliseconds ahead) into this host-bound stretch -- the step
         stays at 20.0 ms either way.  Kept as a tested option for a host whose launch path is cheaper."""
-        self._after_grouping()
         losses = output_dict.get("_point_losses")
         pf = output_dict.get("point_features")
         if (losses is None or pf is None or not pf.requires_grad or not torch.is_grad_enabled()

@@ -49,6 +49,7 @@ class HAIS(GeneralModel):
             cfg.data.point_num_avg, cfg.data.radius_avg, -1)
         proposals_idx = proposals_idx.long()
         proposals_idx[:, 1] = object_idxs[proposals_idx[:, 1]]
+        self._after_grouping()                                 # scheduled work (MS3D_PREFETCH_AT=proposals), also when nothing was grouped
         if proposals_offset.numel() <= 1:
             z = out["point_features"].new_zeros((0, 1))
             out["proposal_scores"] = (z, proposals_idx, proposals_offset, z)

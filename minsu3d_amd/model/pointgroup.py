@@ -93,6 +93,7 @@ class PointGroup(GeneralModel):
         proposals_idx = torch.cat((p_orig, p_shift), dim=0)
         proposals_offset = torch.cat((o_orig, o_shift[1:] + o_orig[-1]))
 
+        self._after_grouping()                                 # scheduled work (MS3D_PREFETCH_AT=proposals), also when nothing was grouped
         if proposals_offset.numel() <= 1:                      # nothing grouped (the reference would crash here)
             out["proposal_scores"] = (out["point_features"].new_zeros((0, 1)), proposals_idx, proposals_offset)
             return out

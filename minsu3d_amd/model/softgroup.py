@@ -117,6 +117,7 @@ class SoftGroup(GeneralModel):
             offsets = out["point_offsets"]
         proposals_idx, proposals_offset = self._soft_grouping(data_dict, sem_scores, offsets)
         out["proposals_idx"], out["proposals_offset"] = proposals_idx, proposals_offset
+        self._after_grouping()                                 # scheduled work (MS3D_PREFETCH_AT=proposals), also when nothing was grouped
         if proposals_offset.numel() <= 1:
             return out
         self._early_point_backward(data_dict, out)     # fills the GPU while the proposal branch is being issued

@@ -8,13 +8,40 @@ import torch
 import torch.distributed as dist
 
 
+def force_process_group():
+    """MS3D_FORCE_PG=1: create the process group and wrap DistributedDataParallel even for ONE rank -- how the RCCL path
+    (communicator, its stream beside the product's, bucket hooks, one-rank all-reduce) is exercised on a single-GPU box"""
+    return os.environ.get("MS3D_FORCE_PG", "0") == "1"
+
+
+def stream_plan(world=None):
+    """Which streams a rank keeps busy.  A process gets 4 hardware queues by default (GPU_MAX_HW_QUEUES); streams beyond
+    that share queues, and a stream that WAITS for another rank (the collective's) on a queue it shares with a stream
+    the other rank is waiting for stalls both until the scheduler rotates (round 5: two ranks on one GPU, every second
+    step 2-20 s).  So under data parallelism the next batch's coordinate prefetch runs on the second grouping stream
+    instead of a stream of its own: main + grouping side + the collective's = 3 (MS3D_PREFETCH_STREAM=own|side overrides).
+    -> dict for the bench line"""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1 or force_process_group()
+    where = os.environ.get("MS3D_PREFETCH_STREAM", "side" if multi else "own")
+    on = os.environ.get("MS3D_PREFETCH_COORDS", "1") != "0"
+    extra = int(os.environ.get("MS3D_WGRAD_STREAM", "0") != "0") + int(os.environ.get("MS3D_EARLY_HEADS", "0") == "2")
+    return {"prefetch_stream": where if on else "off",
+            "compute_streams": 2 + int(on and where == "own") + extra,
+            "collective_streams": "RCCL's own (1+)" if multi else 0,
+            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}
+
+
 def init_distributed():
     """(rank, local_rank, world_size) from the torchrun environment; initialises RCCL when world_size > 1"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_process_group()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # MS3D_DIST_BACKEND=gloo + MS3D_SHARE_DEVICE=1: several ranks on ONE GPU (how the DDP path is exercised on the
         # single-GPU test box; RCCL refuses two ranks on one device)
@@ -67,7 +94,7 @@ def wrap_ddp(model, device, find_unused_parameters=True):
     buffers are left alone during training (80 BatchNorm layers x 3 buffers per step for values only evaluation reads)
     and `sync_buffers()` broadcasts rank 0's before validation and before a checkpoint is written, which is where the
     reference's ranks > 0 would see them."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_process_group()):
         return model
     ids = None if device is None or device.type != "cuda" else [device.index]
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,

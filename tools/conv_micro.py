@@ -40,13 +40,16 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
 g = torch.randn(vout, cout, device=dev)
-for _ in range(3):
-    dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
-e0.record()
-for _ in range(n):
-    dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
-e1.record(); torch.cuda.synchronize()
-us_w = e0.elapsed_time(e1) / n * 1e3
+try:
+    for _ in range(3):
+        dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
+    e0.record()
+    for _ in range(n):
+        dW = be.conv_backward_weight(x, g, nbr, vout, K, cin, cout)
+    e1.record(); torch.cuda.synchronize()
+    us_w = e0.elapsed_time(e1) / n * 1e3
+except Exception:        # shapes the backward-weight kernels do not serve (more than 14 output column blocks: a backward-data twin)
+    us_w = float("nan")
 # the layer entry point (what the modules call): weight images incl. the aux image, fused BatchNorm / ReLU prologue
 scale = torch.rand(cin, device=dev) + 0.5; shift = torch.randn(cin, device=dev) * 0.2
 yl, _, wfb = be.conv_layer_forward(x, W, nbr, vout, K, cin, cout, K == 27, (scale, shift), True, None, None, False)
