@@ -328,6 +328,11 @@ def main(argv=None):
 
     rank, local, world = init_distributed()
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if rank != 0:
+        # stdout belongs to rank 0's JSON line: whatever a library of another rank prints (RCCL's banner, flushed at exit)
+        # goes to stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
     device = torch.device("cpu") if dry else torch.device("cuda", local)
     if not dry:
         torch.cuda.set_device(device)
@@ -451,9 +456,18 @@ def main(argv=None):
             also = "hais,softgroup" if plain else "none"
         if also != "none" and world == 1 and not dry:
             line["extra"] = {m: other_model_line(m, args) for m in also.split(",") if m and m != args.model}
-        print(json.dumps(line), flush=True)
+    # the collective library goes down FIRST and the C stdio buffers are flushed: RCCL prints a version banner through
+    # printf (found in round 6, the first time RCCL ran here: behind a pipe it surfaced AFTER the JSON line) -- rank 0's
+    # JSON line is the last thing this process writes to stdout
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -97,9 +97,18 @@ def wrap_ddp(model, device, find_unused_parameters=True):
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_process_group()):
         return model
     ids = None if device is None or device.type != "cuda" else [device.index]
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
-                                                     broadcast_buffers=False, bucket_cap_mb=25,
-                                                     gradient_as_bucket_view=True)
+    extra = {}
+    if os.environ.get("MS3D_DDP_STATIC", "0") == "1" and not find_unused_parameters:
+        extra["static_graph"] = True      # the autograd graph of a step does not change: skips the per-step graph bookkeeping
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
+                                                    broadcast_buffers=False, bucket_cap_mb=int(os.environ.get("MS3D_DDP_BUCKET_MB", "25")),
+                                                    gradient_as_bucket_view=True, **extra)
+    if os.environ.get("MS3D_DDP_HOOK", "0") == "1":
+        # torch's all-reduce hook divides the FLAT bucket once; without a hook the reducer divides every parameter's
+        # bucket view on its own (~250 small launches per step)
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(None, default_hooks.allreduce_hook)
+    return ddp
 
 
 def sync_buffers(model, src=0):
