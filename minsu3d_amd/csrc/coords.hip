@@ -235,7 +235,7 @@ template <int KT, int RPT>
 __global__ __launch_bounds__(256) void pairlist_count_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
                                                              int *__restrict__ tile_nb)
 {
-    constexpr int H = RPT / 64;
+    constexpr int H = RPT >= 64 ? RPT / 64 : 1, LIVE = RPT >= 64 ? 64 : RPT;   // RPT = 32: the upper half of the wave idles
     const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
     if (tile > tiles) return;
     if (tile == tiles) {  // slot for the grand total of the exclusive scan
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void pairlist_count_kernel(const int *__restri
 #pragma unroll
     for (int h = 0; h < H; h++) {
         const int row = tile * RPT + 64 * h + lane_id();
-        const bool ok = row < Vout;
+        const bool ok = row < Vout && lane_id() < LIVE;
 #pragma unroll
         for (int k = 0; k < KT; k++) {
             const int v = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
@@ -265,7 +265,7 @@ template <int KT, int RPT>
 __global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restrict__ nbr, int K, int Vout, int tiles,
                                                             const int *__restrict__ tile_start, int2 *__restrict__ entries)
 {
-    constexpr int H = RPT / 64;
+    constexpr int H = RPT >= 64 ? RPT / 64 : 1, LIVE = RPT >= 64 ? 64 : RPT;
     const int tile = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
     if (tile >= tiles) return;
     const int l = lane_id();
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void pairlist_fill_kernel(const int *__restric
 #pragma unroll
     for (int h = 0; h < H; h++) {
         const int row = tile * RPT + 64 * h + l;
-        const bool ok = row < Vout;
+        const bool ok = row < Vout && l < LIVE;
 #pragma unroll
         for (int k = 0; k < KT; k++) v[h][k] = (ok && k < K) ? nbr[(size_t)min(k, K - 1) * Vout + (ok ? row : 0)] : -1;
     }
@@ -509,16 +509,18 @@ int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
-    if (K > 27 || (rows_per_tile != 64 && rows_per_tile != 128)) return MS3D_E_UNSUPPORTED;
+    if (K > 27 || (rows_per_tile != 32 && rows_per_tile != 64 && rows_per_tile != 128)) return MS3D_E_UNSUPPORTED;
     if (workspace_bytes < ms3d_scan_workspace_bytes()) return MS3D_E_WORKSPACE;
     const int tiles = ms3d_divup(Vout, rows_per_tile);
     const int grid = ms3d_divup((long)(tiles + 1) * 64, 256);
-    const bool wide = rows_per_tile == 128;
+    const bool wide = rows_per_tile == 128, narrow = rows_per_tile == 32;
     if (K <= 8) {
         if (wide) pairlist_count_kernel<8, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+        else if (narrow) pairlist_count_kernel<8, 32><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
         else pairlist_count_kernel<8, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
     } else {
         if (wide) pairlist_count_kernel<27, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
+        else if (narrow) pairlist_count_kernel<27, 32><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
         else pairlist_count_kernel<27, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start);
     }
     MS3D_LAUNCH_CHECK();
@@ -533,9 +535,11 @@ int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_
     int2 *ent = reinterpret_cast<int2 *>(entries);
     if (K <= 8) {
         if (wide) pairlist_fill_kernel<8, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+        else if (narrow) pairlist_fill_kernel<8, 32><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
         else pairlist_fill_kernel<8, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
     } else {
         if (wide) pairlist_fill_kernel<27, 128><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
+        else if (narrow) pairlist_fill_kernel<27, 32><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
         else pairlist_fill_kernel<27, 64><<<grid, 256, 0, stream>>>(nbr, K, Vout, tiles, tile_start, ent);
     }
     MS3D_LAUNCH_CHECK();

@@ -1458,12 +1458,18 @@ int launch_fwd_ws(const ConvArgs &p, int nblk, int threads, size_t lds, hipStrea
 // Batches run in ascending offset order and a batch holds distinct output rows (pads go to a dummy row), so the
 // per-output summation order is fixed: deterministic, no atomics.  The epilogue streams the tile out row-major
 // (residual / bias / output statistics / fused BN-backward mask and sums exactly as store_tile).
-constexpr int CR = MS3D_PL_ROWS;
+// CR = rows per tile of the list: 64 (ms3d_kmap_pairlist_build), or 32 for 32 -> 32 layers (round 6): their weight image is
+// 110 KB of LDS, and with 8.3 KB accumulator tiles only four waves fit beside it, so rounds 1-5 ran them as two 16-column
+// slices of 12 waves -- every row gathered twice, twice the address / BatchNorm / entry work per MFMA (round-6 counters: the
+// kernel is bound by instruction issue, not bytes).  With 32-row tiles (4.2 KB) nine waves hold both column blocks.
+constexpr int PL_ROWS_NARROW = 32;
 
-__host__ __device__ constexpr size_t pairlist_wave_floats(int nbt) { return (size_t)(CR + 1) * nbt * 16; }
+__host__ __device__ constexpr size_t pairlist_wave_floats(int nbt, int cr = MS3D_PL_ROWS) { return (size_t)(cr + 1) * nbt * 16; }
 
-template <int NBT, int NCH>
-__global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
+// (the narrow form never runs more than 10 waves -- 110 KB of weights + 10 x 4.2 KB -- so it is compiled for 640 threads:
+// 168 registers instead of 128, no scratch in the straight-line batch loop)
+template <int NBT, int NCH, int CR = MS3D_PL_ROWS>
+__global__ __launch_bounds__(CR == PL_ROWS_NARROW ? 640 : 1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
 {
     struct { const float *bias, *bn_scale, *bn_shift, *bn_mean, *bn_invstd; } ep = {p.bias, p.bn_scale, p.bn_shift, p.bn_mean, p.bn_invstd};
     extern __shared__ float lds[];
@@ -1482,7 +1488,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
     const int wslots = p.K * NCH * NBT * 64;
     float *s_part = lds + (size_t)wslots * 4;  // [2*Cout]
     int *s_next = reinterpret_cast<int *>(s_part + ((2 * p.Cout + 3) & ~3));  // tile pick counter (+ 3 pad: 16-B alignment)
-    float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + 4 + (size_t)wave_id() * pairlist_wave_floats(NBT);  // [(CR+1)][CW]
+    float *acc_t = s_part + ((2 * p.Cout + 3) & ~3) + 4 + (size_t)wave_id() * pairlist_wave_floats(NBT, CR);  // [(CR+1)][CW]
 
     const int nblk = gridDim.x;
     const int per_xcd = (nblk + 7) / 8;
@@ -1634,7 +1640,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
                     *dst = cur;
                 }
             };
-            if (NCH * NBT <= 2 && b0 + CBU <= b_end) {
+            if ((NCH * NBT <= 2 || (NCH == 2 && NBT == 2)) && b0 + CBU <= b_end) {
                 // Full group, one straight-line block (register budget: up to two fragments per batch).  The compiler cannot tell the weight image from the accumulator
                 // tile (both LDS), so it keeps every batch's fragment read behind the previous batch's accumulator
                 // write: read -> 4 dependent MFMAs -> read-modify-write, ~330 cycles per batch in sequence.  Program order
@@ -1698,7 +1704,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
         // (per-tile view of the per-column operands: hoisted out of the tile loop they sat in scratch across the pair loop)
         asm volatile("" : "+s"(ep.bias), "+s"(ep.bn_scale), "+s"(ep.bn_shift), "+s"(ep.bn_mean), "+s"(ep.bn_invstd));
 #pragma unroll
-        for (int i = 0; i < F4; i++) {
+        for (int i = 0; i < CR * F4 / 64; i++) {
             const int r = i * (64 / F4) + l / F4;
             f32x4 *src = reinterpret_cast<f32x4 *>(acc_t + acc_slot(r, c4));
             f32x4 o4 = *src;
@@ -1761,19 +1767,19 @@ __global__ __launch_bounds__(1024) void spconv_fwd_pairlist_kernel(ConvArgs p)
             const int which = t >= p.Cout, c = t - which * p.Cout - 16 * nb0;  // column inside this block's slice
             float sum = 0.f;
             if (c >= 0 && c < CW)
-                for (int w = 0; w < waves; w++) sum += wave0[(size_t)w * pairlist_wave_floats(NBT) + which * CW + c];
+                for (int w = 0; w < waves; w++) sum += wave0[(size_t)w * pairlist_wave_floats(NBT, CR) + which * CW + c];
             dst[t] = sum;
         }
     }
 }
 
-template <int NBT, int NCH>
+template <int NBT, int NCH, int CR = MS3D_PL_ROWS>
 int launch_fwd_pairlist(ConvArgs p, dim3 grid, int threads, size_t lds, hipStream_t stream)
 {
     p.ntiles = ms3d_divup(p.Vout, CR);
-    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_pairlist_kernel<NBT, NCH>);
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_fwd_pairlist_kernel<NBT, NCH, CR>);
     MS3D_CHECK(attr);
-    spconv_fwd_pairlist_kernel<NBT, NCH><<<grid, threads, lds, stream>>>(p);
+    spconv_fwd_pairlist_kernel<NBT, NCH, CR><<<grid, threads, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -3329,6 +3335,7 @@ struct FwdGeom {
     size_t lds;
     bool ok, small, pairlist, stream;
     int cg;   // stream kernel: 16-channel chunks per weight group
+    int pl_rows;  // pair-list kernel: rows per tile of the list it walks (64, or 32 for 32 -> 32 layers)
     bool ws;  // weight-stationary kernel of the coarse levels: ws_ng offset groups of ws_kg, ws_R row parts of ws_tpp tiles
     int ws_ng, ws_kg, ws_R, ws_tpp;
 };
@@ -3559,19 +3566,34 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
             const char *e = getenv("MS3D_PL_W");  // tuning knob: cap on waves per block
             return e ? atoi(e) : 0;
         }();
+        int cr = MS3D_PL_ROWS;
         auto waves_for = [&](int nbt_) {
             const size_t wbytes = (size_t)K * NCH * 4 * nbt_ * 64 * sizeof(float);
-            const size_t perwave = pairlist_wave_floats(nbt_) * sizeof(float);
+            const size_t perwave = pairlist_wave_floats(nbt_, cr) * sizeof(float);
             return wbytes + spart >= LDS_BUDGET ? 0 : (int)((LDS_BUDGET - wbytes - spart) / perwave);
         };
         static const int min_waves = [] { const char *e = getenv("MS3D_PL_MIN_WAVES"); return e ? atoi(e) : 8; }();
+        // 32 -> 32 (K = 27): both column blocks in one wave on 32-row tiles when 64-row tiles leave fewer than min_waves.
+        // OPT-IN (MS3D_PL_NARROW=1; default: two 16-column slices on 64-row tiles as in rounds 1-5).  Measured
+        // (profiles/r06_pairlist_narrow.txt, us per launch, slices | narrow): level 1 of the bench batch (196k rows, 10.2 of
+        // 27 neighbours per row) forward 98.9 | 88.8, backward-data side 126.9 | 111.6; level 0 (417k rows, 5.5 neighbours:
+        // where the m = 32 models have their 32-channel layers) 120.8 | 133.7 -- a 32-row tile has 6.5 pairs per offset
+        // there and pads them to 16.  The launch geometry is decided from the layer shape alone (it also sizes the
+        // statistics partials), so the pair density of the table cannot pick the variant; left to the caller.
+        static const int narrow = env_int("MS3D_PL_NARROW", 0);
+        if (narrow && nbt == 2 && NCH == 2 && waves_for(nbt) < min_waves) {
+            cr = PL_ROWS_NARROW;
+            if (waves_for(nbt) < min_waves) cr = MS3D_PL_ROWS;
+        }
         while (nbt > 1 && waves_for(nbt) < min_waves) {   // next smaller divisor of the column-block count
             int d = nbt - 1;
             while (NBtot % d != 0) d--;
             nbt = d;
         }
         int W = waves_for(nbt);
-        const int tiles = ms3d_divup(Vout, CR);
+        if (cr == PL_ROWS_NARROW && W > 10) W = 10;     // the narrow kernel's launch bound
+        const int tiles = ms3d_divup(Vout, cr);
+        g.pl_rows = cr;
         if (W > 16) W = 16;
         if (env_w > 0 && W > env_w) W = env_w;
         if (W >= 2) {
@@ -3584,7 +3606,7 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
             g.threads = W * 64;
             g.nblk = MS3D_PL_PARTS;
             g.G = K;
-            g.lds = (size_t)K * NCH * 4 * nbt * 64 * sizeof(float) + spart + (size_t)W * pairlist_wave_floats(nbt) * sizeof(float);
+            g.lds = (size_t)K * NCH * 4 * nbt * 64 * sizeof(float) + spart + (size_t)W * pairlist_wave_floats(nbt, cr) * sizeof(float);
             g.ok = true;
             return g;
         }
@@ -3652,7 +3674,7 @@ int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0
 int ms3d_spconv_pairlist_rows(int Vout, int K, int Cin, int Cout)
 {
     const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, false, true);
-    return g.stream ? PSR : (g.pairlist ? MS3D_PL_ROWS : 0);
+    return g.stream ? PSR : (g.pairlist ? g.pl_rows : 0);
 }
 
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist)
@@ -3742,6 +3764,7 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
         if (g.nbt == 1 && p.NCH == 1) return launch_fwd_pairlist<1, 1>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 2) return launch_fwd_pairlist<1, 2>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 2 && p.NCH == 1) return launch_fwd_pairlist<2, 1>(p, grid, g.threads, g.lds, stream);
+        if (g.nbt == 2 && p.NCH == 2 && g.pl_rows == PL_ROWS_NARROW) return launch_fwd_pairlist<2, 2, PL_ROWS_NARROW>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 2 && p.NCH == 2) return launch_fwd_pairlist<2, 2>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 3) return launch_fwd_pairlist<1, 3>(p, grid, g.threads, g.lds, stream);
         if (g.nbt == 1 && p.NCH == 4) return launch_fwd_pairlist<1, 4>(p, grid, g.threads, g.lds, stream);
