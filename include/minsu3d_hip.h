@@ -212,6 +212,11 @@ int ms3d_kmap_pairlist_header_ints_rows(int Vout, int rows_per_tile);
 size_t ms3d_kmap_pairlist_capacity_rows(int K, int Vout, int rows_per_tile);
 int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_tile, int *tile_start, int *entries,
                                   void *workspace, size_t workspace_bytes, ms3d_stream_t stream);
+/* rows_per_tile may also be 32 (round 6): the list a 32 -> 32 layer walks with BOTH column blocks in one wave when the table
+ * is dense enough (ms3d_spconv_pairlist_rows_dense).  The library remembers on the host which tile size every list it built
+ * has (keyed by the tile_start address; the newest build at an address wins), so that the convolution entry points -- whose
+ * signatures carry the two list pointers only -- launch the kernel variant the list was built for: */
+int ms3d_kmap_pairlist_rows_of(const int *tile_start);   /* 32 / 64 / 128; 64 for a list this library did not build */
 
 /* Offset-major pair list of a table (the classic per-offset in/out index pairs) for the backward-weight kernel:
  *   kt_start[header_ints]    K * tiles + 1 pair offsets: first pair of (offset k, 64-row tile t) at [k * tiles + t],
@@ -237,10 +242,16 @@ int ms3d_spconv_prep_weights(const float *W, int K, int Cin_eff, int Cout_eff, i
 /* out[i,:] = sum_k act(in[nbr[k][i],:]) @ Weff[k] (+ residual); act = optional x*pre_scale+pre_shift (+ReLU).
  * With bn_x != NULL the epilogue is the backward of a fused BN+ReLU: out = dz = acc * [bn_x*bn_scale+bn_shift > 0]
  * and bn_partial [ms3d_spconv_partial_blocks()][2][Cout] receives per-block sums of dz and dz*xhat. */
-int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist);
+int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist /* 0 = no list; 1 = a 64-row list;
+                               otherwise the list's rows per tile (ms3d_kmap_pairlist_rows_of) */);
 /* rows per tile of the pair list a forward / backward-data convolution of this shape wants in pl_tile_start / pl_entries:
  * 0 = none, 64 = ms3d_kmap_pairlist_build, 128 = ms3d_kmap_pairlist_build_rows(.., 128, ..) */
 int ms3d_spconv_pairlist_rows(int Vout, int K, int Cin, int Cout);
+/* the same for a DENSE table (about 8+ of 27 neighbours per row: every level but the full-resolution one): 32 for the
+ * 32 -> 32 layers (both column blocks per wave on 32-row tiles: every row gathered once instead of once per 16-column
+ * slice; at 5.5 neighbours per row a 32-row tile pads 6.5 pairs per offset to 16 and loses), otherwise
+ * ms3d_spconv_pairlist_rows.  The caller decides from the table's pair count which of the two lists to build. */
+int ms3d_spconv_pairlist_rows_dense(int Vout, int K, int Cin, int Cout);
 /* 1 when the convolution kernels have a pair-list variant worth building the list for (full-resolution levels) */
 int ms3d_kmap_pairlist_wanted(int K, int Vout);
 int ms3d_spconv_forward(const float *in, const float *wf, const int *nbr, int Vout, int K, int Cin, int Cout,

@@ -168,7 +168,8 @@ def _take_prefetched(coordinates):
     for t in list(held):
         if t is not None:
             for pl in (getattr(t, "_ms3d_pairlist", None) or {}).values():      # {rows per tile: (tile_start, entries)}
-                held.extend(x for x in pl if x is not None)
+                if isinstance(pl, tuple):                                       # (+ "dense": the table's density verdict)
+                    held.extend(x for x in pl if x is not None)
             held.extend(x for x in (getattr(t, "_ms3d_offsetlist", None) or ()) if x is not None)
     for t in held:
         if t is not None and t.is_cuda:

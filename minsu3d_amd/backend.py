@@ -888,6 +888,25 @@ class _HipEngine:
         cache = getattr(nbr, "_ms3d_pairlist", None)
         if cache is None:
             cache = nbr._ms3d_pairlist = {}
+        dense_rows = self._geom("ms3d_spconv_pairlist_rows_dense", vout, K, cin, cout)
+        if dense_rows != rows:
+            # a layer shape with a second kernel variant for DENSE tables (32 -> 32: both column blocks per wave on 32-row
+            # tiles).  The table's pair count decides, once per table: a 32-row tile of a full-resolution level (5.5 of 27
+            # neighbours) pads 6.5 pairs per offset to 16 and loses 11 %, at 10 neighbours the variant saves 10-12 %.
+            dense = cache.get("dense")
+            if dense is None:
+                mode = os.environ.get("MS3D_PL_NARROW", "1")
+                if mode == "2":
+                    dense = True
+                else:
+                    pairs = getattr(nbr, "_ms3d_pairs_dev", None)
+                    if pairs is None:
+                        pairs = nbr._ms3d_pairs_dev = (nbr >= 0).sum()
+                    # one device->host read per table; the input pipeline builds the lists on its own thread and stream
+                    dense = float(pairs) >= float(os.environ.get("MS3D_PL_NARROW_DENSITY", "8.0")) * max(int(vout), 1)
+                cache["dense"] = dense
+            if dense:
+                rows = dense_rows
         pl = cache.get(rows)
         if pl is None:
             self.lib.ms3d_kmap_pairlist_capacity_rows.restype = C.c_size_t
@@ -901,6 +920,10 @@ class _HipEngine:
                                                               _lib.stream_handle()), "ms3d_kmap_pairlist_build_rows")
             pl = cache[rows] = (tile_start, entries)
         return pl
+
+    def _pl_rows(self, pl):
+        """rows per tile of a pair list (0 = no list): what ms3d_spconv_partial_blocks wants to know about it"""
+        return int(self.lib.ms3d_kmap_pairlist_rows_of(_lib.ptr(pl[0]))) if pl[0] is not None else 0
 
     def offsetlist(self, nbr, K, vout):
         """offset-major pair list of a table for the backward-weight kernel, cached on the table tensor
@@ -935,7 +958,7 @@ class _HipEngine:
         bnargs = [None] * 5
         pl = self.pairlist(nbr, K, vout, cin, cout)
         if bn_bwd is not None or out_stats:
-            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), int(pl[0] is not None))
+            nparts = self.lib.ms3d_spconv_partial_blocks(int(vout), int(K), int(cin), int(cout), self._pl_rows(pl))
             partial = torch.empty((nparts, 2, cout), dtype=torch.float32, device=x.device)
         if bn_bwd is not None:
             bnargs = [_f32(t) for t in bn_bwd]
@@ -1077,7 +1100,7 @@ class _HipEngine:
         dev = x.device
         wf_buf = wf_ready if wf_ready is not None else torch.empty(self.wf_floats(K, cin, cout), dtype=torch.float32, device=dev)
         pl = self.pairlist(nbr_fwd, K, vout, cin, cout)
-        nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, int(pl[0] is not None)) if want_stats else 0
+        nparts = self._geom("ms3d_spconv_partial_blocks", vout, K, cin, cout, self._pl_rows(pl)) if want_stats else 0
         ps, pb = (pre if pre is not None else (None, None))
         timer = self.kernel_timer
         tok = timer.conv("fwd", K, cin, cout, nbr_fwd, vout) if timer is not None else None

@@ -10,6 +10,8 @@
 //     16 output rows a wave owns read 64 contiguous bytes per offset:
 //       k3 s1 : nbr[k][i] = row at c_i + o_k*ts            (k = ix + 3*iy + 9*iz, x fastest)
 //       k2 s2 : down[k][p] = child of coarse row p at offset k;  up[k][f] = (k == koff[f]) ? parent[f] : -1
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "scan.h"
 #include "../../include/minsu3d_hip.h"
@@ -504,12 +506,29 @@ size_t ms3d_kmap_pairlist_capacity_rows(int K, int Vout, int rows_per_tile)
 }
 size_t ms3d_kmap_pairlist_capacity(int K, int Vout) { return ms3d_kmap_pairlist_capacity_rows(K, Vout, MS3D_PL_ROWS); }
 
+// host-side note of every list's tile size, keyed by the address of its header (see the header file)
+static std::mutex g_pl_rows_lock;
+static std::unordered_map<const int *, int> g_pl_rows;
+int ms3d_kmap_pairlist_rows_of(const int *tile_start)
+{
+    if (!tile_start) return 0;
+    std::lock_guard<std::mutex> guard(g_pl_rows_lock);
+    auto it = g_pl_rows.find(tile_start);
+    return it == g_pl_rows.end() ? MS3D_PL_ROWS : it->second;
+}
+
 int ms3d_kmap_pairlist_build_rows(const int *nbr, int K, int Vout, int rows_per_tile, int *tile_start, int *entries,
                                   void *workspace, size_t workspace_bytes, ms3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (Vout <= 0) return 0;
     if (K > 27 || (rows_per_tile != 32 && rows_per_tile != 64 && rows_per_tile != 128)) return MS3D_E_UNSUPPORTED;
+    {
+        std::lock_guard<std::mutex> guard(g_pl_rows_lock);
+        if (g_pl_rows.size() > 65536)                        // addresses of long-gone lists: entries that say the default go
+            for (auto it = g_pl_rows.begin(); it != g_pl_rows.end();) it = it->second == MS3D_PL_ROWS ? g_pl_rows.erase(it) : std::next(it);
+        g_pl_rows[tile_start] = rows_per_tile;
+    }
     if (workspace_bytes < ms3d_scan_workspace_bytes()) return MS3D_E_WORKSPACE;
     const int tiles = ms3d_divup(Vout, rows_per_tile);
     const int grid = ms3d_divup((long)(tiles + 1) * 64, 256);

@@ -3481,8 +3481,10 @@ bool pairstream_shape_ok(int Vout, int K, int Cin, int Cout)
 constexpr int SMALL_TILES = 1100;  // <= ~17k output rows: direct-B split-K kernel (measured faster than LDS staging up to here)
 // Launch geometry shared by the launcher and ms3d_spconv_partial_blocks.  Small levels (a few hundred rows at the
 // bottom of the U-Net) are spread over the chip by giving each wave fewer output columns and each block fewer waves.
-FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, bool with_pairlist)
+// pl_rows: rows per tile of the pair list the call is given (0 = none)
+FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, int pl_rows)
 {
+    const bool with_pairlist = pl_rows != 0;
     FwdGeom g{};
     const int NCH = ms3d_divup(Cin, 16), NBtot = ms3d_divup(Cout, 16);
     const int ntiles = ms3d_divup(Vout, 16);
@@ -3573,17 +3575,16 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, b
             return wbytes + spart >= LDS_BUDGET ? 0 : (int)((LDS_BUDGET - wbytes - spart) / perwave);
         };
         static const int min_waves = [] { const char *e = getenv("MS3D_PL_MIN_WAVES"); return e ? atoi(e) : 8; }();
-        // 32 -> 32 (K = 27): both column blocks in one wave on 32-row tiles when 64-row tiles leave fewer than min_waves.
-        // OPT-IN (MS3D_PL_NARROW=1; default: two 16-column slices on 64-row tiles as in rounds 1-5).  Measured
-        // (profiles/r06_pairlist_narrow.txt, us per launch, slices | narrow): level 1 of the bench batch (196k rows, 10.2 of
-        // 27 neighbours per row) forward 98.9 | 88.8, backward-data side 126.9 | 111.6; level 0 (417k rows, 5.5 neighbours:
-        // where the m = 32 models have their 32-channel layers) 120.8 | 133.7 -- a 32-row tile has 6.5 pairs per offset
-        // there and pads them to 16.  The launch geometry is decided from the layer shape alone (it also sizes the
-        // statistics partials), so the pair density of the table cannot pick the variant; left to the caller.
-        static const int narrow = env_int("MS3D_PL_NARROW", 0);
-        if (narrow && nbt == 2 && NCH == 2 && waves_for(nbt) < min_waves) {
+        // 32 -> 32 (K = 27): both column blocks in one wave on 32-row tiles when 64-row tiles leave fewer than min_waves --
+        // taken when the call comes with a 32-row list (pl_rows), which the caller builds for DENSE tables only
+        // (ms3d_spconv_pairlist_rows_dense).  Measured (profiles/r06_pairlist_narrow.txt, us per launch, two 16-column
+        // slices on 64-row tiles | narrow): level 1 of the bench batch (196k rows, 10.2 of 27 neighbours per row) forward
+        // 98.9 | 88.8, backward-data side 126.9 | 111.6, and -0.35 ms of convolution time per PointGroup step; level 0
+        // (417k rows, 5.5 neighbours: where the m = 32 models have their 32-channel layers) 120.8 | 133.7 -- a 32-row
+        // tile has 6.5 pairs per offset there and pads them to 16.
+        if (pl_rows == PL_ROWS_NARROW) {
             cr = PL_ROWS_NARROW;
-            if (waves_for(nbt) < min_waves) cr = MS3D_PL_ROWS;
+            if (!(nbt == 2 && NCH == 2 && waves_for(nbt) >= min_waves)) { g.ok = false; return g; }   // not a list this shape can walk
         }
         while (nbt > 1 && waves_for(nbt) < min_waves) {   // next smaller divisor of the column-block count
             int d = nbt - 1;
@@ -3673,13 +3674,22 @@ int ms3d_kmap_pairlist_wanted(int K, int Vout) { return pairlist_min_rows() >= 0
 // small-level kernel), 64 = ms3d_kmap_pairlist_build, 128 = ms3d_kmap_pairlist_build_rows(.., 128, ..)
 int ms3d_spconv_pairlist_rows(int Vout, int K, int Cin, int Cout)
 {
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, false, true);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, false, MS3D_PL_ROWS);
     return g.stream ? PSR : (g.pairlist ? g.pl_rows : 0);
+}
+
+int ms3d_spconv_pairlist_rows_dense(int Vout, int K, int Cin, int Cout)
+{
+    const int plain = ms3d_spconv_pairlist_rows(Vout, K, Cin, Cout);
+    static const int narrow = env_int("MS3D_PL_NARROW", 1);    // 0: never build the 32-row lists
+    if (plain != MS3D_PL_ROWS || !narrow || K != 27 || Cin != 32 || Cout != 32) return plain;
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, false, PL_ROWS_NARROW);
+    return (g.ok && g.pairlist && g.pl_rows == PL_ROWS_NARROW) ? PL_ROWS_NARROW : plain;
 }
 
 int ms3d_spconv_partial_blocks(int Vout, int K, int Cin, int Cout, int with_pairlist)
 {
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true, with_pairlist != 0);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, true, with_pairlist == 1 ? MS3D_PL_ROWS : with_pairlist);
     return g.nblk * g.ny;
 }
 
@@ -3727,7 +3737,8 @@ static int spconv_forward_impl(const float *in, const float *wf, const int *nbr,
     p.residual = residual; p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
     p.bn_invstd = bn_invstd; p.bn_partial = bn_partial; p.Vout = Vout; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.NCH = ms3d_divup(Cin, 16); p.NBtot = ms3d_divup(Cout, 16); p.ntiles = ms3d_divup(Vout, 16); p.pre_relu = pre_relu;
-    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr || p.out_stats, pl_tile_start && pl_entries);
+    const FwdGeom g = fwd_geometry(Vout, K, Cin, Cout, bn_x != nullptr || p.out_stats,
+                                   (pl_tile_start && pl_entries) ? ms3d_kmap_pairlist_rows_of(pl_tile_start) : 0);
     if (!g.ok) return MS3D_E_UNSUPPORTED;
     p.G = g.G;
     dim3 grid(g.nblk, g.ny);
@@ -4254,7 +4265,8 @@ size_t ms3d_spconv_layer_ws_floats(int Vin, int Vout, int K, int Cin, int Cout)
     const size_t wf = ms3d_spconv_wf_floats(K, Cin, Cout) + ms3d_spconv_wf_floats(K, Cout, Cin);
     const auto blocks = [](int V, int K_, int ci, int co) {
         const int a = ms3d_spconv_partial_blocks(V, K_, ci, co, 0), b = ms3d_spconv_partial_blocks(V, K_, ci, co, 1);
-        return (size_t)(a > b ? a : b);
+        const int c = ms3d_spconv_partial_blocks(V, K_, ci, co, ms3d_spconv_pairlist_rows_dense(V, K_, ci, co));
+        return (size_t)(a > b ? (a > c ? a : c) : (b > c ? b : c));
     };
     const size_t pf = blocks(Vout, K, Cin, Cout) * 2 * Cout;
     const size_t pb = blocks(Vin, K, Cout, Cin) * 2 * Cin;
@@ -4383,7 +4395,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
             ev_stop = nullptr;
         } else {
             if (!pre_relu) return MS3D_E_UNSUPPORTED;  // BN without ReLU in front of a conv: handled by the generic path
-            const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, pl_bwd_tile_start && pl_bwd_entries);
+            const int nparts = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, (pl_bwd_tile_start && pl_bwd_entries)
+                                                                                 ? ms3d_kmap_pairlist_rows_of(pl_bwd_tile_start) : 0);
             float *partial = ws;
             rc = spconv_forward_impl(dy, wft, nbr_bwd, Vin, K, Cout, Cin, dx, nullptr, nullptr, 0, nullptr, x, scale, shift,
                                      mean, invstd, partial, 0, nullptr, pl_bwd_tile_start, pl_bwd_entries, wfts, aux_kind,
@@ -4415,7 +4428,8 @@ int ms3d_spconv_layer_backward(const float *x, const float *dy, const float *wf_
         return 0;
     }
     const int pb0 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 0), pb1 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, 1);
-    slabs = ws + (size_t)(pb0 > pb1 ? pb0 : pb1) * 2 * Cin;
+    const int pb2 = ms3d_spconv_partial_blocks(Vin, K, Cout, Cin, ms3d_spconv_pairlist_rows_dense(Vin, K, Cout, Cin));
+    slabs = ws + (size_t)(pb0 > pb1 ? (pb0 > pb2 ? pb0 : pb2) : (pb1 > pb2 ? pb1 : pb2)) * 2 * Cin;
     return run_wgrad();
 }
 

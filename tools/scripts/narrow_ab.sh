@@ -1,0 +1,15 @@
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1
+timeout 900 python -m pytest tests/test_sparse_gpu.py tests/test_determinism_gpu.py -x -q 2>&1 | tail -4
+run() { echo "== $*"; env "$@" python3 bench.py --model ${MS3D_MODEL:-pointgroup} --steps 40 --warmup 6 --no-cpu-baseline --also none 2>gpurun_out/ab_err.txt | python3 -c "
+import sys, json
+d = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print(d['value'], d['step_ms']['median'], 'conv ms', d['roofline']['kernel_ms_per_step'], 'frac', d['roofline']['frac'])" || tail -5 gpurun_out/ab_err.txt; }
+for rep in 1 2; do
+run MS3D_PL_NARROW=0
+run MS3D_PL_NARROW=1
+done
+run MS3D_PL_NARROW=0 MS3D_MODEL=hais
+export MS3D_MODEL=hais
+run MS3D_PL_NARROW=0
+run MS3D_PL_NARROW=1
+run MS3D_PL_NARROW=2
