@@ -374,6 +374,55 @@ def test_pair_lists_bit_exact(be, oracle, K, scene):
             assert np.all(seg[len(r):, 0] == 0) and np.all(seg[len(r):, 1] == ((k << 8) | 64))
 
 
+def test_narrow_pair_list_bit_exact_and_its_kernel_vs_oracle(be, oracle):
+    """round 6: the 32-row-tile list of the 32 -> 32 layers (both column blocks per wave) -- the list against a numpy
+    restatement of its definition, the library's host-side note of its tile size, and (child process, MS3D_PL_NARROW=2:
+    the variant for EVERY table, whatever its density) the convolution kernel that walks it through the same parity
+    checks as every other pair-list shape, incl. the skewed scene whose parts hold between 1 and ~50 tiles"""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from minsu3d_amd import _lib
+    rng = np.random.default_rng(32)
+    c = surface_coords(rng, 2, 200000, 300)
+    nbr = oracle.kmap_k3(c, 1).T.copy()
+    K, V, R = 27, nbr.shape[1], 32
+    nbr_d = dev(nbr)
+    lib = be.lib
+    lib.ms3d_kmap_pairlist_capacity_rows.restype = C.c_size_t
+    tile_start = torch.empty(lib.ms3d_kmap_pairlist_header_ints_rows(V, R), dtype=torch.int32, device="cuda")
+    entries = torch.empty((lib.ms3d_kmap_pairlist_capacity_rows(K, V, R), 2), dtype=torch.int32, device="cuda")
+    ws = be._cws(1, nbr_d.device)
+    _lib.check(lib.ms3d_kmap_pairlist_build_rows(_lib.ptr(nbr_d), K, V, R, _lib.ptr(tile_start), _lib.ptr(entries), _lib.ptr(ws),
+                                                 C.c_size_t(ws.numel()), _lib.stream_handle()), "build_rows")
+    assert lib.ms3d_kmap_pairlist_rows_of(_lib.ptr(tile_start)) == R
+    assert lib.ms3d_spconv_pairlist_rows_dense(V, K, 32, 32) == R and lib.ms3d_spconv_pairlist_rows(V, K, 32, 32) == 64
+    assert lib.ms3d_spconv_pairlist_rows_dense(V, K, 16, 16) == 64
+    tiles = (V + R - 1) // R
+    kk, rows = np.nonzero(nbr >= 0)
+    cnt = np.zeros((K, tiles), np.int64)
+    np.add.at(cnt, (kk, rows // R), 1)
+    nb = (cnt.T + 15) // 16
+    want_ts = np.concatenate([[0], np.cumsum(nb.sum(1))])
+    ts_host = tile_start.cpu().numpy()
+    assert np.array_equal(ts_host[:tiles + 1], want_ts)
+    ent = entries[:16 * int(want_ts[-1])].cpu().numpy()
+    starts = 16 * (want_ts[:-1, None] + np.cumsum(nb, 1) - nb)
+    for t in rng.integers(0, tiles, 60):
+        for k in range(K):
+            r = np.nonzero(nbr[k, t * R:(t + 1) * R] >= 0)[0]
+            seg = ent[starts[t, k]: starts[t, k] + 16 * nb[t, k]]
+            assert np.array_equal(seg[:len(r), 0], nbr[k, t * R + r]) and np.array_equal(seg[:len(r), 1], (k << 8) | r)
+            assert np.all(seg[len(r):, 0] == 0) and np.all(seg[len(r):, 1] == ((k << 8) | R))
+    env = dict(os.environ, MS3D_PL_NARROW="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_sparse_gpu.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "(pair_compacted and 32-32-27) or (skewed and 32-32) or (adjoint and 32)"], env=env,
+                       cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_list_kernels_on_small_and_ragged_levels():
     """the pair-list / offset-list kernels are selected by row count; forced on for every size (the knob is read once
     per process, hence the child process) they must pass the same parity checks on the small, ragged test shapes"""
