@@ -1,6 +1,6 @@
 # usage: bash tools/scripts/pmc_traffic.sh <model> <commit> [tag]  -> gpurun_out/<tag>_traffic_<model>.json
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1; export TMPDIR=/tmp
-M=$1; C=$2; TAG=${3:-r05}
+M=$1; C=$2; TAG=${3:-r06}
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$ctr
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o p -- python3 bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
