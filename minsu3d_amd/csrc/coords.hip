@@ -135,6 +135,25 @@ __global__ void kmap_k3_kernel(const int *__restrict__ coords, int V, int ts, co
     nbr[(size_t)k * V + i] = r;
 }
 
+// The same table from HALF the lookups (round 6): j = nbr[k][i] <=> i = nbr[26 - k][j], so offsets 0..12 are looked up and
+// every hit also writes its mirror entry (each (26 - k, j) has at most one such writer; the rest of offsets 14..26 was
+// pre-filled with -1).  A full-resolution level is 27 x 427k probes of which 80 % miss and walk to an empty slot: the
+// lookups, not the stores, are what the kernel costs (it runs on the input pipeline's stream inside the grouping window).
+__global__ void kmap_k3_sym_kernel(const int *__restrict__ coords, int V, int ts, const unsigned long long *__restrict__ keys,
+                                   const int *__restrict__ vals, unsigned mask, int *__restrict__ nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;          // 0..13
+    if (i >= V) return;
+    if (k == 13) { nbr[(size_t)13 * V + i] = i; return; }
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const int x = c.y + (k % 3 - 1) * ts, y = c.z + ((k / 3) % 3 - 1) * ts, z = c.w + (k / 9 - 1) * ts;
+    int r = -1;
+    if (in_range(x) && in_range(y) && in_range(z)) r = table_lookup(keys, vals, mask, pack_key(c.x, x, y, z));
+    nbr[(size_t)k * V + i] = r;
+    if (r >= 0) nbr[(size_t)(26 - k) * V + r] = i;
+}
+
 __global__ void fill_minus1_kernel(int *p, long n)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,8 +462,15 @@ int ms3d_kmap_k3(const int *coords, int V, int tensor_stride, int *nbr, void *wo
     if (carve(w, V, workspace) > workspace_bytes) return MS3D_E_WORKSPACE;
     int rc = build_table(w, coords, V, 1, stream);
     if (rc) return rc;
-    dim3 grid(ms3d_divup(V, 256), 27);
-    kmap_k3_kernel<<<grid, 256, 0, stream>>>(coords, V, tensor_stride, w.keys, w.vals, (unsigned)w.H - 1u, nbr);
+    static const bool sym = [] { const char *e = getenv("MS3D_KMAP_SYM"); return !e || atoi(e) != 0; }();
+    if (sym) {
+        MS3D_CHECK(hipMemsetAsync(nbr + (size_t)14 * V, 0xFF, sizeof(int) * (size_t)13 * V, stream));
+        dim3 grid(ms3d_divup(V, 256), 14);
+        kmap_k3_sym_kernel<<<grid, 256, 0, stream>>>(coords, V, tensor_stride, w.keys, w.vals, (unsigned)w.H - 1u, nbr);
+    } else {
+        dim3 grid(ms3d_divup(V, 256), 27);
+        kmap_k3_kernel<<<grid, 256, 0, stream>>>(coords, V, tensor_stride, w.keys, w.vals, (unsigned)w.H - 1u, nbr);
+    }
     MS3D_LAUNCH_CHECK();
     return 0;
 }
