@@ -37,7 +37,7 @@ def _restore_backend():
 # training machinery, and the multi-process data-parallel test last -- so that `-x` stops as late as possible and a
 # failure in the machinery cannot hide the kernel suites behind it.  Files not listed run (in alphabetical order) behind
 # the listed parity / pin suites and in front of the machinery tests (bench launch line, multi-process DDP).
-_ORDER = ["test_oracle_grouping", "test_abi_cpu", "test_grouping_gpu", "test_sparse_cpu", "test_sparse_gpu", "test_ws_gpu",
+_ORDER = ["test_oracle_grouping", "test_abi_cpu", "test_host_logic_cpu", "test_grouping_gpu", "test_sparse_cpu", "test_sparse_gpu", "test_ws_gpu",
           "test_fullsize_gpu", "test_dropin_cpu", "test_dropin_gpu", "test_reference_pins_cpu", "test_reference_pins_gpu",
           "test_forward_pins_cpu", "test_forward_pins_gpu", "test_postprocess_cpu", "test_postprocess_gpu",
           "test_transform_cpu", "test_dataset_cpu", "test_dataset_gpu", "test_dataset_pins_cpu", "test_dataset_pins_gpu",
