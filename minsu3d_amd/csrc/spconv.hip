@@ -2662,12 +2662,17 @@ constexpr int WGRAD_TB = 2;  // 16-pair batches per trip
 
 // NCH = 16-channel input chunks handled by one workgroup (blockIdx.z selects the group): the entries and the dout rows
 // of a batch are fetched once for all of them instead of once per chunk.
-template <int NBT, int NCH>
-__global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs p)
+// waves a workgroup of this instantiation can hold (150 KB of LDS, <= 16): its launch bound, so that the variants with large
+// per-wave areas get the registers of the waves they cannot run anyway
+constexpr int wgrad_list_wave_kb(int nbt, int nch, int tb) { return tb * (nch + nbt) > 2 * nch * nbt ? tb * (nch + nbt) : 2 * nch * nbt; }
+constexpr int wgrad_list_max_waves(int nbt, int nch, int tb) { return 150 / wgrad_list_wave_kb(nbt, nch, tb) > 16 ? 16 : 150 / wgrad_list_wave_kb(nbt, nch, tb); }
+
+template <int NBT, int NCH, int TB = WGRAD_TB>
+__global__ __launch_bounds__(64 * wgrad_list_max_waves(NBT, NCH, TB)) void spconv_wgrad_offsetlist_kernel(WgradArgs p)
 {
-    constexpr int TB = WGRAD_TB;
     constexpr int NT = NCH + NBT;   // 16x16 tiles parked per batch
     constexpr int NA = NCH * NBT;   // accumulators
+    constexpr int WAVE_KB = TB * NT > 2 * NA ? TB * NT : 2 * NA;   // the wave's LDS area: tiles, later its boundary partials
     extern __shared__ float lds[];
     __shared__ int s_lo[32], s_cum[33], s_pk[16][2];
     const int l = lane_id(), q = l >> 4, cl = l & 15;
@@ -2676,8 +2681,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     // most two) boundary partials [2][NA*256] -- 2 NA <= TB (NCH + NBT) for every instantiation.  (Rounds 1-5 kept a separate
     // [nw][2][NA*256] area: 8 of the 18 KB per wave at 64 -> 64, which left 8 waves per CU -- round 6 counters: 44 % of the wave
     // cycles waiting, MFMA pipe 36 % busy.)  The FIRST partial of a wave is done long before its loop ends: it waits in registers.
-    static_assert(2 * NA <= TB * NT, "boundary partials reuse the transposition tiles");
-    float *s_tile = lds + (size_t)w * TB * NT * 256;
+    float *s_tile = lds + (size_t)w * WAVE_KB * 256;
     const int tiles = (p.Vout + MS3D_PL_ROWS - 1) / MS3D_PL_ROWS;
     // tile range of this workgroup: 2^rows_per_block consecutive parts of the list's equal-pair-count cut
     const int *__restrict__ part_start = p.ol_kt_start + (size_t)p.K * tiles + 1;
@@ -2857,7 +2861,7 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
             for (int jj = 0; jj < 2; jj++)
                 if (s_pk[ww][jj] == k) {
                     any = true;
-                    const float *src = lds + (size_t)ww * TB * NT * 256 + (size_t)jj * NA * 256;
+                    const float *src = lds + (size_t)ww * WAVE_KB * 256 + (size_t)jj * NA * 256;
 #pragma unroll
                     for (int b = 0; b < NA; b++)
 #pragma unroll
@@ -2867,20 +2871,21 @@ __global__ __launch_bounds__(1024) void spconv_wgrad_offsetlist_kernel(WgradArgs
     }
 }
 
-template <int NBT, int NCH>
+template <int NBT, int NCH, int TB = WGRAD_TB>
 int launch_wgrad_offsetlist(const WgradArgs &p, int nblk_rows, hipStream_t stream)
 {
-    // per wave: WGRAD_TB x (NCH + NBT) transposition tiles of 1 KB (the boundary partials reuse them)
-    const size_t per_wave = (size_t)WGRAD_TB * (NCH + NBT) * 256 * sizeof(float);
+    // per wave: TB x (NCH + NBT) transposition tiles of 1 KB (the boundary partials, 2 x NCH x NBT KB, reuse them)
+    constexpr int wave_kb = TB * (NCH + NBT) > 2 * NCH * NBT ? TB * (NCH + NBT) : 2 * NCH * NBT;
+    const size_t per_wave = (size_t)wave_kb * 256 * sizeof(float);
     static const int max_w = env_int("MS3D_WGRAD_LIST_WAVES", 16);
     int nw = (int)(LDS_BUDGET / per_wave);
     if (nw > 16) nw = 16;
     if (nw > max_w && max_w >= 1) nw = max_w;
     dim3 grid(nblk_rows, ms3d_divup(p.NBtot, NBT), ms3d_divup(ms3d_divup(p.Cin, 16), NCH));
     const size_t lds = (size_t)nw * per_wave;
-    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH>);
+    static const hipError_t attr = raise_lds_ceiling((const void *)spconv_wgrad_offsetlist_kernel<NBT, NCH, TB>);
     MS3D_CHECK(attr);
-    spconv_wgrad_offsetlist_kernel<NBT, NCH><<<grid, nw * 64, lds, stream>>>(p);
+    spconv_wgrad_offsetlist_kernel<NBT, NCH, TB><<<grid, nw * 64, lds, stream>>>(p);
     MS3D_LAUNCH_CHECK();
     return 0;
 }
@@ -3977,7 +3982,15 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
     // (us per launch with 256 / 128 / 64 / 32 parts: 64 -> 64 at 196k rows 396 / 343 / 320 / 589, at 50k 143 / 141 / 122 /
     // 193, 48 -> 48 at 196k 232 / 231 / 215 / 394; the narrow layers want all 256: 32 -> 32 at 417k 124 / 190 / 321)
     static const int list_wide_chunks = [] { const char *e = getenv("MS3D_WGRAD_LIST_WIDE_CHUNKS"); return e ? atoi(e) : 64; }();
-    if (use_list && ms3d_divup(Cin, 16) >= 3 && chunks > list_wide_chunks) chunks = list_wide_chunks;
+    // 64 output channels from 64+ input channels (K = 27; round 6): TWO input chunks per workgroup -- the dout rows (256 B per
+    // pair) are fetched once per two chunks instead of once per chunk, 768 instead of 1280 gathered bytes per pair -- on 128
+    // parts (the grid keeps 256 workgroups), one batch per trip (the second chunk's rows take the registers of the second
+    // batch).  us per launch, one chunk x 64 parts | two chunks x 128 parts: 64 -> 64 at 196k rows 320-328 | 269-271, at 51k
+    // rows 122.6 | 112; 48 -> 48 (three column blocks) does not gain (74.5 | 78 at 51k rows) and keeps one chunk.
+    // MS3D_WGRAD_LIST_NCH2=0: one chunk as before.
+    static const int nch2 = env_int("MS3D_WGRAD_LIST_NCH2", 1);
+    const bool wide2 = nch2 && use_list && K == 27 && p.NBtot == 4 && Cin % 32 == 0 && Cin >= 64;
+    if (use_list && ms3d_divup(Cin, 16) >= 3 && chunks > list_wide_chunks) chunks = wide2 ? 2 * list_wide_chunks : list_wide_chunks;
     if (use_list) {
         // workgroups = the list's MS3D_PL_PARTS equal-pair-count parts, merged in pairs until there are <= chunks
         int shift = 0;
@@ -4014,7 +4027,7 @@ static int spconv_backward_weight_impl(const float *in, const float *dout, const
         rc = nbs == 1 ? (two ? launch_wgrad_offsetlist<1, 2>(p, nblk, stream) : launch_wgrad_offsetlist<1, 1>(p, nblk, stream))
            : nbs == 2 ? (two ? launch_wgrad_offsetlist<2, 2>(p, nblk, stream) : launch_wgrad_offsetlist<2, 1>(p, nblk, stream))
            : nbs == 3 ? launch_wgrad_offsetlist<3, 1>(p, nblk, stream)
-                      : launch_wgrad_offsetlist<4, 1>(p, nblk, stream);
+                      : (wide2 ? launch_wgrad_offsetlist<4, 2, 1>(p, nblk, stream) : launch_wgrad_offsetlist<4, 1>(p, nblk, stream));
         if (rc) return rc;
         if (defer_nblk) { *defer_nblk = nblk; return 0; }
         launch_wgrad_reduce(partial_ws, nblk, n, dW, stream);
