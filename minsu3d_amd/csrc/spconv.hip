@@ -3539,10 +3539,15 @@ FwdGeom fwd_geometry(int Vout, int K, int Cin, int Cout, bool with_bn_partial, i
         // -- two per SIMD, so one wave's loads / LDS updates / register shuffling issue under the other's MFMAs (with one
         // wave per SIMD and 64-column tiles the compiler's straight-line MFMA blocks left the rest un-overlapped: 360 us
         // at 64 -> 64 against 150 us of matrix-pipe time) -- at the price of gathering the input rows once per slice.
-        static const int env_nbt = [] { const char *e = getenv("MS3D_PS_NBT"); return e ? atoi(e) : 2; }();
+        static const int env_nbt = [] { const char *e = getenv("MS3D_PS_NBT"); return e ? atoi(e) : 0; }();
         static const int env_w = [] { const char *e = getenv("MS3D_PS_W"); return e ? atoi(e) : 8; }();
         int nbt = 1, cg = 1;
-        for (int c = env_nbt; c >= 1; c--)
+        // Round 6: K = 27 layers whose column-block count is a multiple of four take all four blocks in one wave (the rows are
+        // gathered once instead of once per two-block slice; eight 35 KB tiles do not fit, the launch runs 4 waves): 32 -> 64
+        // at 196k rows 273 -> 218 us, the backward-data side of 64 -> 32 284 -> 254; three-block slices lose (32 -> 48, K = 8:
+        // 34.7 -> 44.2) and keep the two-block rule.  MS3D_PS_NBT=n: at most n blocks per wave, as before.
+        const int max_nbt = env_nbt > 0 ? env_nbt : ((K == 27 && NBtot % 4 == 0) ? 4 : 2);
+        for (int c = max_nbt; c >= 1; c--)
             if (NBtot % c == 0) { nbt = c; break; }
         for (int c = 4; c >= 1; c--)
             if (NCH % c == 0) { cg = c; break; }
