@@ -895,15 +895,20 @@ class _HipEngine:
             # neighbours) pads 6.5 pairs per offset to 16 and loses 11 %, at 10 neighbours the variant saves 10-12 %.
             dense = cache.get("dense")
             if dense is None:
+                import threading
                 mode = os.environ.get("MS3D_PL_NARROW", "1")
                 if mode == "2":
                     dense = True
-                else:
+                elif mode == "3" or threading.current_thread().name.startswith("ms3d-prefetch"):
+                    # one device->host read per table -- ONLY on the input pipeline's thread (ME.prefetch_coordinates builds
+                    # the lists there, on its own stream): on the calling thread the read would drain the queue the
+                    # interpreter has run ahead of, which costs more than the variant saves.  (3 = read wherever it is asked)
                     pairs = getattr(nbr, "_ms3d_pairs_dev", None)
                     if pairs is None:
                         pairs = nbr._ms3d_pairs_dev = (nbr >= 0).sum()
-                    # one device->host read per table; the input pipeline builds the lists on its own thread and stream
                     dense = float(pairs) >= float(os.environ.get("MS3D_PL_NARROW_DENSITY", "8.0")) * max(int(vout), 1)
+                else:
+                    dense = False          # a table built on the calling thread: the 64-row list (deterministic per configuration)
                 cache["dense"] = dense
             if dense:
                 rows = dense_rows
