@@ -1219,9 +1219,10 @@ int launch_fwd(const ConvArgs &p, dim3 grid, int threads, size_t lds, bool align
 // image: 160 -> 160 at 2.6k rows streams 162 x 2.8 MB through L2 for 3 MB of rows, and a launch is a chain of ~45 dependent
 // L2 round trips per wave.  Here the WEIGHTS stay put:
 //   block  = (offset group g of kg offsets, column slice c of NBT blocks, row part r of tpp tiles); its slab
-//            W[k_lo..k_lo+kg)[all Cin][NBT*16] (<= 64 KB, two blocks per CU) is copied into LDS ONCE and every tile of the part
-//            runs through it -- weights leave L2 (row parts) x |W| per launch instead of (tiles) x |W|;
-//   wave   = tiles w, w + 4, .. of the part; per tile the (offset, 16-channel chunk) items of the group are walked in ONE flat
+//            W[k_lo..k_lo+kg)[all Cin][NBT*16] (MS3D_WS_LDS_KB: 128 KB and 16 waves by default, measured best; the first build
+//            used 64 KB and two 4-wave blocks per CU) is copied into LDS ONCE and every tile of the part runs through it --
+//            weights leave L2 (row parts) x |W| per launch instead of (tiles) x |W|;
+//   wave   = tiles w, w + waves, .. of the part; per tile the (offset, 16-channel chunk) items of the group are walked in ONE flat
 //            sequence, WS_RB row gathers in flight and the next WS_RB behind them (two register sets): a tile costs two
 //            dependent round trips (table entries -- fetched a tile ahead -- and rows) whatever Cin is; B fragments are
 //            conflict-free ds_read_b32 rows of the slab; offsets no row of the tile has skip their MFMAs;
