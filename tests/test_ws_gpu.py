@@ -75,3 +75,56 @@ def test_default_route_serves_the_wide_rectangular_layers(oracle):
     if os.environ.get("MS3D_WS_MAX_TILES", "220") != "0" and os.environ.get("MS3D_WS_ALL", "0") != "1":
         assert blocks_ws < blocks_tiles
     torch.cuda.synchronize()
+
+
+_STRESS = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+from oracle import oracle as O
+O.lib()
+import test_sparse_gpu as T
+from minsu3d_amd.backend import HipBackend
+be = HipBackend()
+rng = np.random.default_rng(7)
+ref = {}
+shapes = [(160, 160, 2700, 60), (320, 160, 2700, 60), (96, 96, 520, 26), (224, 224, 115, 12)]
+data = []
+for cin, cout, npts, extent in shapes:
+    c = T.surface_coords(rng, 2, npts, extent)
+    nbr = T.dev(O.kmap_k3(c, 1).T.copy())
+    x = torch.randn(c.shape[0], cin, device="cuda"); W = torch.randn(27, cin, cout, device="cuda") * 0.05
+    res = torch.randn(c.shape[0], cout, device="cuda")
+    wf = be.prep_weights(W, 27, cin, cout)
+    y, st = be.conv_forward(x, wf, nbr, c.shape[0], 27, cin, cout, residual=res, out_stats=True)
+    torch.cuda.synchronize()
+    data.append((x, wf, nbr, c.shape[0], cin, cout, res, y.clone(), st.clone()))
+# uneven load: a side stream keeps the chip (and the L2s) busy with streaming copies and matrix products of varying size
+# while the split-K launches run back to back on two other streams; every word of every result is compared
+side = torch.cuda.Stream(); s2 = torch.cuda.Stream()
+big = torch.randn(64 << 20, device="cuda"); a = torch.randn(2048, 2048, device="cuda")
+bad = 0
+for it in range(40):
+    with torch.cuda.stream(side):
+        for k in range(1 + it %% 4):
+            big2 = big[: (8 << 20) * (1 + (it + k) %% 7)].clone()
+            a2 = a @ a
+    outs = []
+    for j, (x, wf, nbr, V, cin, cout, res, y0, st0) in enumerate(data):
+        with torch.cuda.stream(s2 if (it + j) %% 2 else torch.cuda.current_stream()):
+            outs.append(be.conv_forward(x, wf, nbr, V, 27, cin, cout, residual=res, out_stats=True))
+    torch.cuda.synchronize()
+    for (y, st), d in zip(outs, data):
+        bad += int(not (torch.equal(y, d[7]) and torch.equal(st, d[8])))
+assert bad == 0, bad
+print("WS_STRESS_OK")
+"""
+
+
+def test_split_k_hand_off_under_uneven_load():
+    """the in-launch combine (release fence -> ticket -> acquire -> plain loads) with the chip busy on other streams and the
+    same launches alternating between two streams: 40 rounds x 4 shapes, every result word for word equal to the idle-chip
+    result (a stale partial tile would show as a different sum)"""
+    env = dict(os.environ, MS3D_WS_ALL="1")
+    out = subprocess.run([sys.executable, "-c", _STRESS % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900,
+                         cwd=ROOT)
+    assert out.returncode == 0 and "WS_STRESS_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
