@@ -1127,6 +1127,22 @@ class _HipEngine:
             ev0, ev1, _lib.stream_handle()), "ms3d_spconv_layer_forward")
         return y, stats, wf_buf
 
+    def res_block_forward(self, x, stats_in, wf1, wf2, nbr, V, c, bn0, g0, b0, bn1, g1, b1, want_stats):
+        """the four library calls of an identity-skip residual block's forward from ONE host call (csrc_host/ms3d_host.cpp:
+        res_block_forward) -> (y1, y2, stats of y2 or None, bn0 = (mean, invstd, scale, shift), bn1 = ...), or None when the
+        fast path does not apply (no host extension, a sampled step of the kernel timer, an unusual BatchNorm)"""
+        ext = self.ext
+        timer = self.kernel_timer
+        if (ext is None or (timer is not None and getattr(timer, "sampling", True)) or not hasattr(ext, "res_block_forward")
+                or os.environ.get("MS3D_RESBLOCK_EXT", "1") == "0"):
+            return None
+        pl = self.pairlist(nbr, 27, V, c, c)
+        nparts = self._geom("ms3d_spconv_partial_blocks", V, 27, c, c, self._pl_rows(pl))
+        y1, y2, st2, o0, o1 = ext.res_block_forward(
+            x, stats_in, wf1, wf2, nbr, V, c, pl[0], pl[1], nparts, bool(want_stats), _f32(g0), _f32(b0), bn0.running_mean,
+            bn0.running_var, bn0.eps, bn0.momentum, _f32(g1), _f32(b1), bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
+        return y1, y2, st2, o0.unbind(0), o1.unbind(0)
+
     def conv_layer_backward(self, x, dy, wf_buf, nbr_fwd, nbr_bwd, vin, vout, K, cin, cout, bn, need_dx, dx_add=None,
                             defer=None, join_now=False):
         """-> (dx or None, dgb [2,cin] = (dbeta, dgamma) or None, dW [K,cin,cout]).  dx_add [vin, cin]: a gradient that

@@ -110,6 +110,43 @@ at::Tensor bn_finalize(const at::Tensor &partial, int64_t V, double eps, double 
     return outs;
 }
 
+// An identity-skip residual block's forward in training mode -- bn_finalize, fused convolution, bn_finalize, fused convolution
+// with the residual in its epilogue -- from ONE call (round 6): the same four library calls functional.ResBlockFn makes, in the
+// same order on the same stream, minus three trips through the interpreter and the backend's per-call bookkeeping (the
+// proposal network issues ~145 launches with the GPU waiting for each: interpreter time is what that stretch of a step
+// costs).  Both weight buffers must already hold the current images (prepare_conv_weights).
+// -> (y1 [V, C], y2 [V, C], stats of y2 [nparts, 2, C] or None, (mean, invstd, scale, shift) of bn0 [4, C], of bn1 [4, C])
+std::tuple<at::Tensor, at::Tensor, OptT, at::Tensor, at::Tensor> res_block_forward(
+    const at::Tensor &x, const at::Tensor &stats_in, at::Tensor wf1, at::Tensor wf2, const at::Tensor &nbr, int64_t V, int64_t C,
+    const OptT &pl_tile_start, const OptT &pl_entries, int64_t nparts, bool want_stats, const OptT &g0, const OptT &b0,
+    OptT rm0, OptT rv0, double eps0, double mom0, const OptT &g1, const OptT &b1, OptT rm1, OptT rv1, double eps1, double mom1)
+{
+    TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.scalar_type() == at::kFloat && x.size(1) == C, "x: contiguous f32 [V, C]");
+    TORCH_CHECK(stats_in.dim() == 3 && stats_in.size(2) == C && stats_in.is_contiguous(), "stats_in: [nparts, 2, C]");
+    auto rs = [](OptT &t) -> float * { return t.has_value() && t->defined() ? t->data_ptr<float>() : nullptr; };
+    const ms3d_stream_t st = cur();
+    at::Tensor bn0 = at::empty({4, C}, x.options()), bn1 = at::empty({4, C}, x.options());
+    float *o0 = bn0.data_ptr<float>(), *o1 = bn1.data_ptr<float>();
+    check(ms3d_bn_finalize(stats_in.data_ptr<float>(), (int)stats_in.size(0), (long)V, (int)C, (float)eps0, (float)mom0, fptr(g0),
+                           fptr(b0), rs(rm0), rs(rv0), o0, o0 + C, o0 + 2 * C, o0 + 3 * C, st), "ms3d_bn_finalize");
+    at::Tensor y1 = at::empty({V, C}, x.options()), st1 = at::empty({nparts, 2, C}, x.options());
+    check(ms3d_spconv_layer_forward(x.data_ptr<float>(), nullptr, nbr.data_ptr<int>(), (int)V, 27, (int)C, (int)C, 1, o0 + 2 * C,
+                                    o0 + 3 * C, 1, nullptr, nullptr, wf1.data_ptr<float>(), y1.data_ptr<float>(),
+                                    st1.data_ptr<float>(), iptr(pl_tile_start), iptr(pl_entries), nullptr, nullptr, st),
+          "ms3d_spconv_layer_forward");
+    check(ms3d_bn_finalize(st1.data_ptr<float>(), (int)nparts, (long)V, (int)C, (float)eps1, (float)mom1, fptr(g1), fptr(b1),
+                           rs(rm1), rs(rv1), o1, o1 + C, o1 + 2 * C, o1 + 3 * C, st), "ms3d_bn_finalize");
+    at::Tensor y2 = at::empty({V, C}, x.options());
+    OptT st2;
+    if (want_stats) st2 = at::empty({nparts, 2, C}, x.options());
+    check(ms3d_spconv_layer_forward(y1.data_ptr<float>(), nullptr, nbr.data_ptr<int>(), (int)V, 27, (int)C, (int)C, 1, o1 + 2 * C,
+                                    o1 + 3 * C, 1, x.data_ptr<float>(), nullptr, wf2.data_ptr<float>(), y2.data_ptr<float>(),
+                                    st2.has_value() ? st2->data_ptr<float>() : nullptr, iptr(pl_tile_start), iptr(pl_entries),
+                                    nullptr, nullptr, st),
+          "ms3d_spconv_layer_forward");
+    return {y1, y2, st2, bn0, bn1};
+}
+
 at::Tensor gather_rows(const at::Tensor &x, const at::Tensor &idx)
 {
     TORCH_CHECK(x.is_cuda() && x.is_contiguous() && idx.is_contiguous() && idx.scalar_type() == at::kLong &&
@@ -127,4 +164,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("conv_layer_backward", &conv_layer_backward);
     m.def("bn_finalize", &bn_finalize);
     m.def("gather_rows", &gather_rows);
+    m.def("res_block_forward", &res_block_forward);
 }
